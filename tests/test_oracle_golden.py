@@ -1,0 +1,165 @@
+"""Pin oracle/wdsr_oracle.py (the CPU restatement) against golden vectors that
+oracle/make_golden.py captured from the reference itself.
+CPU only."""
+import argparse
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wdsr_oracle as O
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def _close(got, exp, rel=3e-6, msg=None):
+    """fp32 restatement vs reference: agree to a few ulps of the tensor's scale
+    (the only arithmetic difference is the rounding order inside weight-norm)."""
+    scale = max(float(exp.abs().max()), 1e-30)
+    err = float((got.detach() - exp).abs().max())
+    assert err <= rel * scale, f"{msg or ''} max|diff| {err:.3e} > {rel:g} * {scale:.3e}"
+
+
+def _sd(d, prefix="p/"):
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+
+
+def test_g1_model_forward_backward(golden_dir):
+    d = _load(golden_dir, "g1_basic_model_c1.npz")
+    sd = {k: v.clone().requires_grad_(True) for k, v in _sd(d).items()}
+    x = d["x"].clone().requires_grad_(True)
+    y = O.basic_model_forward(x, sd, scale=4, image_mean=0.5)
+    assert y.shape == (1, 3, 192, 192)
+    _close(y, d["y"])
+    loss = torch.nn.functional.l1_loss(y, d["hr"])
+    torch.testing.assert_close(loss, d["loss"], rtol=1e-6, atol=1e-7)
+    loss.backward()
+    _close(x.grad, d["dx"], rel=1e-4)
+    for k, p in sd.items():
+        _close(p.grad, d["g/" + k], rel=1e-4, msg=k)
+
+
+def test_g1_module_breadcrumb_and_keys(golden_dir):
+    d = _load(golden_dir, "g1_basic_model_c1.npz")
+    ns = argparse.Namespace(image_mean=0.5, num_channels=3, scale=4, num_blocks=4, num_residual_units=24)
+    m = O.OracleBasicModel(ns)
+    assert set(m.state_dict().keys()) == set(_sd(d).keys())
+    assert sum(p.numel() for p in m.parameters()) == 58984
+    m.load_state_dict(_sd(d), strict=True)
+    y = m(d["x"])
+    _close(y, d["y"])
+    # init values restated from basic_wdsr_b.py:40,62,75,115,126,136
+    m0 = O.OracleBasicModel(ns)
+    assert float(m0.body[0].body[0].weight_g[0]) == 2.0
+    assert float(m0.body[0].body[3].weight_g[0]) == pytest.approx(1 / math.sqrt(4))
+    assert float(m0.head.weight_g[0]) == 1.0 and float(m0.tail.bias.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("f", [24, 32])
+def test_g2_block(golden_dir, f):
+    d = _load(golden_dir, f"g2_block_f{f}.npz")
+    sd = {k: v.clone().requires_grad_(True) for k, v in _sd(d).items()}
+    x = d["x"].clone().requires_grad_(True)
+    y, h, t, r = O.block_forward(x, sd, "body", return_intermediates=True)
+    for got, key in ((y, "y"), (h, "h"), (t, "t"), (r, "r")):
+        _close(got, d[key], msg=key)
+    y.backward(d["dy"])
+    _close(x.grad, d["dx"], rel=1e-5)
+    for k, p in sd.items():
+        _close(p.grad, d["g/" + k], rel=1e-4, msg=k)
+
+
+def test_g3_pretrained_x2(golden_dir):
+    d = _load(golden_dir, "g3_pretrained_x2_8_24.npz")
+    sd = _sd(d)
+    assert len(sd) == 81                                             # SURVEY section 2 "pretrained weights"
+    y = O.basic_model_forward(d["x"], sd, scale=2)
+    _close(y, d["y"])
+    ns = argparse.Namespace(image_mean=0.5, num_channels=3, scale=2, num_blocks=8, num_residual_units=24)
+    m = O.OracleBasicModel(ns)
+    m.load_state_dict(sd, strict=True)
+
+
+def test_g4_pixel_shuffle_bit_exact(golden_dir):
+    d = _load(golden_dir, "g4_pixel_shuffle.npz")
+    for r in (2, 3, 4):
+        assert torch.equal(O.pixel_shuffle(d[f"x_r{r}"], r), d[f"y_r{r}"])
+
+
+def test_g5_rounding_and_binary_mask(golden_dir):
+    d = _load(golden_dir, "g5_binary_mask.npz")
+    for name in ("all_keep", "straddle", "fallback", "ties"):
+        w = d[f"{name}/w"]
+        for lc in (8, 0):
+            assert torch.equal(O.rounding(w, lc), d[f"{name}/mask_lc{lc}"]), (name, lc)
+        wp = w.clone().requires_grad_(True)
+        x = d[f"{name}/x"].clone().requires_grad_(True)
+        y = O.binary_mask_forward(x, wp, 8)
+        assert torch.equal(y, d[f"{name}/y"])
+        y.backward(d[f"{name}/dy"])
+        torch.testing.assert_close(x.grad, d[f"{name}/dx"], rtol=0, atol=0)
+        torch.testing.assert_close(wp.grad, d[f"{name}/dw"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("f", [24, 32])
+def test_g6_split_block(golden_dir, f):
+    d = _load(golden_dir, f"g6_split_block_f{f}.npz")
+    sd = {k: v.clone().requires_grad_(True) for k, v in _sd(d).items()}
+    x = d["x"].clone().requires_grad_(True)
+    y = O.split_block_forward_body(x, sd)
+    _close(y, d["y"])
+    y.backward(d["dy"])
+    _close(x.grad, d["dx"], rel=1e-5)
+    for k in d:
+        if k.startswith("g/"):
+            _close(sd[k[2:]].grad, d[k], rel=1e-4, msg=k)
+    # beta is never used in forward: the reference leaves its grad None
+    assert "g/beta" not in d and sd["beta"].grad is None
+
+
+def test_g7_vsr_trunk(golden_dir):
+    d = _load(golden_dir, "g7_vsr_trunk.npz")
+    sd = {k: v.clone().requires_grad_(True) for k, v in _sd(d).items()}
+    x = d["x"].clone().requires_grad_(True)
+    y = O.conv_residual_blocks_forward(x, sd, "main")
+    _close(y, d["y"])
+    y.backward(d["dy"])
+    _close(x.grad, d["dx"], rel=1e-5)
+    for k, p in sd.items():
+        _close(p.grad, d["g/" + k], rel=1e-4, msg=k)
+
+
+def test_g8_flow_warp(golden_dir):
+    d = _load(golden_dir, "g8_flow_warp.npz")
+    x = d["x"].clone().requires_grad_(True)
+    fl = d["flow"].clone().requires_grad_(True)
+    y = O.flow_warp(x, fl)
+    torch.testing.assert_close(y, d["y"], rtol=0, atol=1e-6)
+    y.backward(d["dy"])
+    torch.testing.assert_close(x.grad, d["dx"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(fl.grad, d["dflow"], rtol=1e-4, atol=1e-5)
+
+
+def test_g9_psnr_hand_cases():
+    """common/metrics.py is not importable (skimage/mmedit absent): the
+    restatement is pinned by hand-computed cases."""
+    hr = torch.full((1, 3, 16, 16), 0.5)
+    sr = hr + 1.0 / 255.0
+    # quantise: (0.5+1/255)*255 = 128.5 -> round-half-even 128 -> 128/255; diff = 128/255-0.5 = 0.5/255
+    exp = -10 * math.log10((0.5 / 255) ** 2)
+    assert float(O.psnr(sr, hr, shave=4)) == pytest.approx(exp, abs=1e-3)
+    sr2 = hr + 2.0 / 255.0      # 129.5 -> 130 (half-even) -> diff 2.5/255
+    assert float(O.psnr(sr2, hr, shave=4)) == pytest.approx(-10 * math.log10((2.5 / 255) ** 2), abs=1e-3)
+    # psnr_y: no quantisation (the reference drops `r`), luma weights on the difference
+    e = 1.0 / 255.0
+    exp_y = -10 * math.log10(((0.257 + 0.504 + 0.098) * e) ** 2)
+    assert float(O.psnr_y(hr + e, hr, shave=4)) == pytest.approx(exp_y, abs=1e-3)
+    # batch is summed, not averaged (metrics.py:19)
+    assert float(O.psnr_y(torch.cat([hr + e] * 3), torch.cat([hr] * 3), shave=2)) == pytest.approx(3 * exp_y, abs=3e-3)
+    # clamp to [0,1] before the difference
+    assert float(O.psnr_y(torch.full_like(hr, 1.5), torch.ones_like(hr) - e, shave=0)) == pytest.approx(exp_y, abs=1e-3)
