@@ -1,0 +1,54 @@
+/* sr_hotpath.h -- C ABI of libsr_hotpath.so: the MI355X (gfx950) kernels behind the
+ * WDSR-B / BasicVSR super-resolution hot path of zhuzhui-2000/mobilesuperresolution.
+ *
+ * The reference has no FFI of its own: its boundary is the nn.Module surface
+ * (models/__init__.py:31-32 get_model, models/basic_wdsr_b.py:85-93 BASIC_MODEL.forward).  This
+ * header is the seam *beneath* that surface: the Python mirror in mobilesuperresolution_amd/models
+ * binds these entry points with ctypes (see INTEGRATION.md for the binding a maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed from the caller (PyTorch allocator); nothing is
+ *     allocated, freed or synchronised inside; all work is enqueued on `stream` (a hipStream_t).
+ *   - activations are NHWC ("pixel-major, channels innermost"); dtype: 0 = float32 (exact-fp32 MFMA,
+ *     parity mode), 1 = bfloat16 storage with fp32 accumulation (throughput mode).
+ *   - weights arrive as "packed fragment blobs" built on the host by
+ *     mobilesuperresolution_amd/packing.py from the effective (weight-normalised) tensors.
+ *   - return value: 0 on success, a hipError_t value on a launch error, -1 unsupported geometry,
+ *     -2 bad argument.  Entry points are re-entrant and hold no global mutable state (autograd calls
+ *     the backward ones from its own thread).
+ */
+#ifndef SR_HOTPATH_H
+#define SR_HOTPATH_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sr_stream_t; /* hipStream_t */
+
+#define SR_DTYPE_F32 0
+#define SR_DTYPE_BF16 1
+
+/* ABI version of this header (bumped on any signature change). */
+int sr_abi_version(void);
+
+/* Fused residual block forward.  Replaces Block.forward, models/basic_wdsr_b.py:142-144 (body of
+ * :108-138): y = conv3x3(conv1x1(relu(conv1x1(x)))) + x on an N x H x W x F NHWC tensor.
+ * Supported (F, E, L): (24,144,20), (32,192,26).  wblob / cinit: packing.block_fwd_tables(). */
+int sr_wdsr_block_fwd(const void* x, void* y, const void* wblob, const float* cinit,
+                      int N, int H, int W, int F, int dtype, sr_stream_t stream);
+
+/* ---- hardware probes used by tests/test_gpu_probe.py (lane maps the kernels rely on) ---- */
+int sr_probe_mfma_bf16(const void* a_frag, const void* b_frag, float* acc_out, sr_stream_t stream);
+int sr_probe_mfma_f32(const float* a_frag, const float* b_frag, float* acc_out, sr_stream_t stream);
+int sr_probe_tr_read(const void* img_bf16, int n_elems, const int* lane_elem_off, void* out_bf16x4,
+                     sr_stream_t stream);
+/* streaming copy of n_bytes (multiple of 16): the achievable-HBM-bandwidth yardstick for bench.py */
+int sr_probe_copy(const void* src, void* dst, size_t n_bytes, sr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SR_HOTPATH_H */

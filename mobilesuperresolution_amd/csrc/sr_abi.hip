@@ -1,0 +1,88 @@
+// C-ABI entry points of libsr_hotpath.so (declared in include/sr_hotpath.h).
+#include "../../include/sr_hotpath.h"
+#include "wdsr_block.h"
+
+extern "C" int sr_abi_version(void) { return 1; }
+
+namespace {
+
+template <typename T, int F, int E, int L>
+int launch_block_fwd(const void* x, void* y, const void* wblob, const float* cinit, int N, int H, int W,
+                     hipStream_t st) {
+  typedef BlockCfg<F, E, L> C;
+  const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
+  dim3 grid(tiles_x * tiles_y, N), block(256);
+  hipLaunchKernelGGL((wdsr_block_fwd_kernel<T, F, E, L>), grid, block, 0, st, (const T*)x, (T*)y, (const T*)wblob,
+                     cinit, H, W, tiles_x);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int sr_wdsr_block_fwd(const void* x, void* y, const void* wblob, const float* cinit, int N, int H,
+                                 int W, int F, int dtype, sr_stream_t stream) {
+  if (!x || !y || !wblob || !cinit || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  if (F == 24 && dtype == SR_DTYPE_BF16) return launch_block_fwd<__bf16, 24, 144, 20>(x, y, wblob, cinit, N, H, W, st);
+  if (F == 24 && dtype == SR_DTYPE_F32) return launch_block_fwd<float, 24, 144, 20>(x, y, wblob, cinit, N, H, W, st);
+  if (F == 32 && dtype == SR_DTYPE_BF16) return launch_block_fwd<__bf16, 32, 192, 26>(x, y, wblob, cinit, N, H, W, st);
+  if (F == 32 && dtype == SR_DTYPE_F32) return launch_block_fwd<float, 32, 192, 26>(x, y, wblob, cinit, N, H, W, st);
+  return -1;
+}
+
+// ------------------------------------------------------------------------------------------
+// probes
+// ------------------------------------------------------------------------------------------
+__global__ void probe_mfma_bf16_kernel(const bf16x8* a, const bf16x8* b, float* out) {
+  const int l = threadIdx.x;
+  f32x16 acc = zero16();
+  acc = mma16<__bf16>(a[l], b[l], acc);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) out[l * 16 + i] = acc[i];
+}
+__global__ void probe_mfma_f32_kernel(const f32x8* a, const f32x8* b, float* out) {
+  const int l = threadIdx.x;
+  f32x16 acc = zero16();
+  acc = mma16<float>(a[l], b[l], acc);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) out[l * 16 + i] = acc[i];
+}
+__global__ void probe_tr_kernel(const __bf16* img, int n, const int* off, bf16x4* out) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[8192];
+  for (int i = threadIdx.x; i < n && i < 8192; i += 64) lds[i] = img[i];
+  __syncthreads();
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  out[threadIdx.x] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lds + off[threadIdx.x]));
+}
+__global__ void probe_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
+extern "C" int sr_probe_mfma_bf16(const void* a, const void* b, float* out, sr_stream_t stream) {
+  hipLaunchKernelGGL(probe_mfma_bf16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16x8*)a,
+                     (const bf16x8*)b, out);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int sr_probe_mfma_f32(const float* a, const float* b, float* out, sr_stream_t stream) {
+  hipLaunchKernelGGL(probe_mfma_f32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const f32x8*)a,
+                     (const f32x8*)b, out);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int sr_probe_tr_read(const void* img, int n, const int* off, void* out, sr_stream_t stream) {
+  if (n > 8192) return -2;
+  hipLaunchKernelGGL(probe_tr_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const __bf16*)img, n, off,
+                     (bf16x4*)out);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int sr_probe_copy(const void* src, void* dst, size_t n_bytes, sr_stream_t stream) {
+  if (n_bytes % 16) return -2;
+  hipLaunchKernelGGL(probe_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src,
+                     (u32x4*)dst, n_bytes / 16);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,107 @@
+// Device-side building blocks shared by every kernel of the SR hot path (gfx950 / CDNA4 only).
+//
+// Conventions (wave64, lane l: r = l & 31, hh = l >> 5), all on v_mfma_f32_32x32x16_bf16 or, in the
+// exact-fp32 parity mode, on 8 x v_mfma_f32_32x32x2_f32 per 16-deep k-step:
+//   * a "fragment" is 8 elements per lane.  As the A operand lane (r,hh) holds A[row r][k = 8*hh + j],
+//     as the B operand it holds B[k = 8*hh + j][col r], j = 0..7.  The fp32 form keeps the same
+//     (lane, j) -> (row|col, k) meaning; MFMA #j contracts k in {j, 8 + j}.
+//   * an accumulator tile is 32x32 fp32: reg i of lane (r,hh) holds D[row (i&3) + 8*(i>>2) + 4*hh][col r].
+//   * an accumulator tile used as the next product's B operand ("chained" k order): k-step s takes
+//     regs 8s..8s+7, i.e. element j of lane half hh is row 16s + 8*(j>>2) + 4*hh + (j&3); the other
+//     operand is packed on the host in that same order (mobilesuperresolution_amd/packing.py).
+//   * swapping the two operand registers of an MFMA yields the transposed tile, so the same packed
+//     weight fragments serve "channels in rows, pixels on lanes" and "pixels in rows, channels on lanes".
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define SR_DEV __device__ __forceinline__
+
+template <typename T> struct FragOf;
+template <> struct FragOf<__bf16> { typedef bf16x8 type; typedef bf16x4 half_type; };
+template <> struct FragOf<float>  { typedef f32x8 type;  typedef f32x4 half_type; };
+
+// D = A*B + C over one 16-deep k-step.
+template <typename T> SR_DEV f32x16 mma16(typename FragOf<T>::type a, typename FragOf<T>::type b, f32x16 c);
+template <> SR_DEV f32x16 mma16<__bf16>(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <> SR_DEV f32x16 mma16<float>(f32x8 a, f32x8 b, f32x16 c) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+  return c;
+}
+
+// accumulator regs 8s..8s+7 -> fragment (chained k order)
+template <typename T, int S> SR_DEV typename FragOf<T>::type acc_to_frag(const f32x16& acc) {
+  typename FragOf<T>::type f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (T)acc[8 * S + j];
+  return f;
+}
+
+// accumulator regs 4g..4g+3 (rows 8g + 4hh + 0..3) -> 4 packed elements
+template <typename T> SR_DEV typename FragOf<T>::half_type acc_group(const f32x16& acc, int g) {
+  typename FragOf<T>::half_type v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = (T)acc[4 * g + j];
+  return v;
+}
+
+SR_DEV f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+// C-init table: float[2][16] per tile (lane half hh, reg i) -> accumulator
+SR_DEV f32x16 load_cinit(const float* __restrict__ tab, int hh) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(tab + hh * 16);
+  f32x16 c;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 v = p[q];
+    c[4 * q + 0] = v[0]; c[4 * q + 1] = v[1]; c[4 * q + 2] = v[2]; c[4 * q + 3] = v[3];
+  }
+  return c;
+}
+
+// packed weight fragment #idx (64 lanes x 8 elements, lane-major) from global memory
+template <typename T> SR_DEV typename FragOf<T>::type load_wfrag(const T* __restrict__ w, int idx, int lane) {
+  return *reinterpret_cast<const typename FragOf<T>::type*>(w + ((size_t)idx * 64 + lane) * 8);
+}
+
+// 8 consecutive elements from an LDS image (16-byte aligned element offset)
+template <typename T> SR_DEV typename FragOf<T>::type lds_chunk(const T* img, int elem_off) {
+  return *reinterpret_cast<const typename FragOf<T>::type*>(img + elem_off);
+}
+
+// ---- transposed fragment: element j = img[px(j)][ch] for 8 pixel rows and this lane's channel ----
+// bf16: ds_read_b64_tr_b16.  Within each 16-lane group the instruction reads a 4-row x 16-column block:
+// lane 4q+p of the group supplies the address of row q, columns 4p..4p+3; lane i receives column i of
+// the 4 rows.  Our lane (r,hh): group = r>>4 picks channels 16*(r>>4) .. +15; rows are 4 pixels.
+// `rowaddr_lo/hi` = element offsets of THIS lane's supplied row (q = (lane>>2)&3) for the two
+// 4-pixel groups, pointing at channel 16*(r>>4) + 4*(lane&3).
+SR_DEV bf16x8 lds_tr_frag(const __bf16* img, int rowaddr_lo, int rowaddr_hi) {
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + rowaddr_lo));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + rowaddr_hi));
+  bf16x8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+
+template <typename T> SR_DEV T relu(T x) { return x > (T)0 ? x : (T)0; }
+
+#define SR_HIP_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -1,0 +1,59 @@
+"""CPU checks of the host packing tables + the wave-level algorithm (numpy MFMA
+emulation, tests/mfma_emu.py) against the reference's golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mobilesuperresolution_amd import packing as P
+from oracle import wdsr_oracle as O
+from tests import mfma_emu as M
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def block_src(d, geom):
+    w = [O.weight_norm(d[f"p/body.{i}.weight_v"], d[f"p/body.{i}.weight_g"]).reshape(-1) for i in (0, 2, 3)]
+    b = [d[f"p/body.{i}.bias"] for i in (0, 2, 3)]
+    src = torch.cat(w + b + [torch.tensor([0.0, 1.0])]).double().numpy()
+    assert src.size == geom.off["size"]
+    return src
+
+
+@pytest.mark.parametrize("f", [24, 32])
+def test_block_fwd_tables_match_golden(golden_dir, f):
+    d = _load(golden_dir, f"g2_block_f{f}.npz")
+    tab = P.block_fwd_tables(f, 6 * f, int(f * 0.84))
+    g = tab["geom"]
+    src = block_src(d, g)
+    pw, ci = src[tab["w"]], src[tab["cinit"]]
+    assert pw.size == (tab["n_w1"] + tab["n_w2"] + tab["n_w3"]) * 512
+    x = d["x"][0].permute(1, 2, 0).double().numpy()          # (H, W, F) = 20 x 28: partial tiles
+    y = M.emu_block_fwd(x, pw, ci, g, dtype="f32")
+    exp = d["y"][0].permute(1, 2, 0).double().numpy()
+    err = np.abs(y - exp).max()
+    assert err <= 3e-6 * np.abs(exp).max(), err
+
+
+def test_block_fwd_bf16_emulation_tolerance(golden_dir):
+    d = _load(golden_dir, "g2_block_f24.npz")
+    tab = P.block_fwd_tables(24, 144, 20)
+    g = tab["geom"]
+    src = block_src(d, g)
+    x = d["x"][0].permute(1, 2, 0).double().numpy()[:12, :24]
+    exp = O.block_forward(torch.from_numpy(x).float().permute(2, 0, 1)[None], {k[2:]: v for k, v in d.items() if k.startswith("p/")})
+    y = M.emu_block_fwd(x, src[tab["w"]], src[tab["cinit"]], g, dtype="bf16")
+    exp = exp[0].permute(1, 2, 0).double().numpy()
+    rel = np.abs(y - exp).max() / np.abs(exp).max()
+    assert rel < 2e-2, rel        # bf16 storage/operands, fp32 accumulate
+
+
+def test_geometry_constants():
+    g = P.BlockGeom(24, 144, 20)
+    assert (g.KX, g.KS1, g.NET, g.KS2, g.LP, g.CPT, g.KS3) == (32, 2, 5, 9, 24, 3, 15)
+    g = P.BlockGeom(32, 192, 26)
+    assert (g.KX, g.KS1, g.NET, g.KS2, g.LP, g.CPT, g.KS3) == (32, 2, 6, 12, 32, 4, 20)
