@@ -40,6 +40,24 @@ int sr_abi_version(void);
 int sr_wdsr_block_fwd(const void* x, void* y, const void* wblob, const float* cinit,
                       int N, int H, int W, int F, int dtype, sr_stream_t stream);
 
+/* Fused residual block backward w.r.t. its input.  Replaces autograd's backward of Block.forward
+ * (models/basic_wdsr_b.py:142-144): dx = dy + W1^T[1(h>0) * W2^T conv3x3^T(dy)], h recomputed from x.
+ * wblob / cinit: packing.block_tables() (forward sections first). */
+int sr_wdsr_block_bwd_data(const void* x, const void* dy, void* dx, const void* wblob, const float* cinit,
+                           int N, int H, int W, int F, int dtype, sr_stream_t stream);
+
+/* Weight/bias gradients of `layers` residual blocks in one call.  Layer i reads x + i*x_ls,
+ * dy + i*dy_ls, wblob + i*w_ls, cinit + i*c_ls (strides in elements).  Every workgroup writes one
+ * partial slab: partial_a[layers][wgs_per_layer][slab_a] (dW1, dW2, db1, db2) and
+ * partial_b[layers][wgs_per_layer][slab_b] (dW3, db3) in accumulator layout; the caller sums over
+ * the workgroup axis and gathers with packing.block_grad_tables().  sr_wdsr_block_slab_sizes returns
+ * the slab lengths (floats). */
+int sr_wdsr_block_wgrad(const void* x, const void* dy, const void* wblob, const float* cinit,
+                        float* partial_a, float* partial_b, int layers, int wgs_per_layer,
+                        int N, int H, int W, int F, int dtype,
+                        long x_ls, long dy_ls, long w_ls, long c_ls, sr_stream_t stream);
+int sr_wdsr_block_slab_sizes(int F, int* slab_a, int* slab_b);
+
 /* ---- hardware probes used by tests/test_gpu_probe.py (lane maps the kernels rely on) ---- */
 int sr_probe_mfma_bf16(const void* a_frag, const void* b_frag, float* acc_out, sr_stream_t stream);
 int sr_probe_mfma_f32(const float* a_frag, const float* b_frag, float* acc_out, sr_stream_t stream);

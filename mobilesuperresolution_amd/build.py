@@ -39,13 +39,45 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-I", os.path.join(HERE, "..", "include")]
+           "-Rpass-analysis=kernel-resource-usage", "-I", os.path.join(HERE, "..", "include")]
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    report = parse_resource_usage(res.stderr)
+    if res.returncode != 0:
+        sys.stderr.write(res.stderr)
+        raise RuntimeError("hipcc failed")
+    with open(os.path.join(HERE, "kernel_resources.txt"), "w") as f:
+        for k in report:
+            f.write("{name} vgpr={vgpr} agpr={agpr} spill={spill} scratch={scratch} lds={lds} occ={occ}\n".format(**k))
+    bad = [k for k in report if k["spill"] or k["scratch"]]
+    if bad:
+        # ROCm 7.2 hipcc miscompiles a partially spilled fragment (see csrc/sr_common.h): never ship a spill
+        raise RuntimeError("register spills in: " + ", ".join(f"{k['name']} (spill {k['spill']})" for k in bad))
     os.replace(LIB + ".tmp", LIB)
     return LIB
+
+
+def parse_resource_usage(text: str):
+    import re
+    out, cur = [], None
+    pats = {"vgpr": r" VGPRs: (\d+)", "agpr": r"AGPRs: (\d+)", "spill": r"VGPRs Spill: (\d+)",
+            "scratch": r"ScratchSize \[bytes/lane\]: (\d+)", "lds": r"LDS Size \[bytes/block\]: (\d+)",
+            "occ": r"Occupancy \[waves/SIMD\]: (\d+)"}
+    for line in text.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = {"name": m.group(1), "vgpr": 0, "agpr": 0, "spill": 0, "scratch": 0, "lds": 0, "occ": 0}
+            out.append(cur)
+            continue
+        if cur is None:
+            continue
+        for k, p in pats.items():
+            m = re.search(p, line)
+            if m:
+                cur[k] = int(m.group(1))
+    return out
 
 
 if __name__ == "__main__":

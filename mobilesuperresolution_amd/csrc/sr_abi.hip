@@ -18,7 +18,70 @@ int launch_block_fwd(const void* x, void* y, const void* wblob, const float* cin
   return 0;
 }
 
+template <typename T, int F, int E, int L>
+int launch_block_bwd_data(const void* x, const void* dy, void* dx, const void* wblob, const float* cinit, int N,
+                          int H, int W, hipStream_t st) {
+  typedef BlockCfg<F, E, L> C;
+  const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
+  dim3 grid(tiles_x * tiles_y, N), block(256);
+  hipLaunchKernelGGL((wdsr_block_bwd_data_kernel<T, F, E, L>), grid, block, 0, st, (const T*)x, (const T*)dy, (T*)dx,
+                     (const T*)wblob, cinit, H, W, tiles_x);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int F, int E, int L>
+int launch_block_wgrad(const void* x, const void* dy, const void* wblob, const float* cinit, float* pa, float* pb,
+                       int layers, int wgs, int N, int H, int W, long x_ls, long dy_ls, long w_ls, long c_ls,
+                       hipStream_t st) {
+  typedef BlockCfg<F, E, L> C;
+  const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
+  dim3 grid(wgs, layers), block(256);
+  hipLaunchKernelGGL((wdsr_block_wgrad12_kernel<T, F, E, L>), grid, block, 0, st, (const T*)x, (const T*)dy,
+                     (const T*)wblob, cinit, pa, N, H, W, tiles_x, tiles_x * tiles_y, x_ls, dy_ls, w_ls, c_ls);
+  SR_HIP_CHECK_LAUNCH();
+  hipLaunchKernelGGL((wdsr_block_wgrad3_kernel<T, F, E, L>), grid, block, 0, st, (const T*)x, (const T*)dy,
+                     (const T*)wblob, cinit, pb, N, H, W, tiles_x, tiles_x * tiles_y, x_ls, dy_ls, w_ls, c_ls);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+
 }  // namespace
+
+extern "C" int sr_wdsr_block_bwd_data(const void* x, const void* dy, void* dx, const void* wblob,
+                                      const float* cinit, int N, int H, int W, int F, int dtype,
+                                      sr_stream_t stream) {
+  if (!x || !dy || !dx || !wblob || !cinit || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  if (F == 24 && dtype == SR_DTYPE_BF16) return launch_block_bwd_data<__bf16, 24, 144, 20>(x, dy, dx, wblob, cinit, N, H, W, st);
+  if (F == 24 && dtype == SR_DTYPE_F32) return launch_block_bwd_data<float, 24, 144, 20>(x, dy, dx, wblob, cinit, N, H, W, st);
+  if (F == 32 && dtype == SR_DTYPE_BF16) return launch_block_bwd_data<__bf16, 32, 192, 26>(x, dy, dx, wblob, cinit, N, H, W, st);
+  if (F == 32 && dtype == SR_DTYPE_F32) return launch_block_bwd_data<float, 32, 192, 26>(x, dy, dx, wblob, cinit, N, H, W, st);
+  return -1;
+}
+
+extern "C" int sr_wdsr_block_wgrad(const void* x, const void* dy, const void* wblob, const float* cinit,
+                                   float* pa, float* pb, int layers, int wgs, int N, int H, int W, int F,
+                                   int dtype, long x_ls, long dy_ls, long w_ls, long c_ls, sr_stream_t stream) {
+  if (!x || !dy || !wblob || !cinit || !pa || !pb || layers <= 0 || wgs <= 0 || N <= 0 || H <= 0 || W <= 0 ||
+      layers > 65535)
+    return -2;
+  hipStream_t st = (hipStream_t)stream;
+#define SR_WG(T, F_, E_, L_) launch_block_wgrad<T, F_, E_, L_>(x, dy, wblob, cinit, pa, pb, layers, wgs, N, H, W, x_ls, dy_ls, w_ls, c_ls, st)
+  if (F == 24 && dtype == SR_DTYPE_BF16) return SR_WG(__bf16, 24, 144, 20);
+  if (F == 24 && dtype == SR_DTYPE_F32) return SR_WG(float, 24, 144, 20);
+  if (F == 32 && dtype == SR_DTYPE_BF16) return SR_WG(__bf16, 32, 192, 26);
+  if (F == 32 && dtype == SR_DTYPE_F32) return SR_WG(float, 32, 192, 26);
+#undef SR_WG
+  return -1;
+}
+
+extern "C" int sr_wdsr_block_slab_sizes(int F, int* slab_a, int* slab_b) {
+  if (!slab_a || !slab_b) return -2;
+  if (F == 24) { *slab_a = BwdCfg<BlockCfg<24, 144, 20>>::SLAB_A; *slab_b = BwdCfg<BlockCfg<24, 144, 20>>::SLAB_B; return 0; }
+  if (F == 32) { *slab_a = BwdCfg<BlockCfg<32, 192, 26>>::SLAB_A; *slab_b = BwdCfg<BlockCfg<32, 192, 26>>::SLAB_B; return 0; }
+  return -1;
+}
 
 extern "C" int sr_wdsr_block_fwd(const void* x, void* y, const void* wblob, const float* cinit, int N, int H,
                                  int W, int F, int dtype, sr_stream_t stream) {

@@ -81,6 +81,20 @@ template <typename T> SR_DEV typename FragOf<T>::type load_wfrag(const T* __rest
   return *reinterpret_cast<const typename FragOf<T>::type*>(w + ((size_t)idx * 64 + lane) * 8);
 }
 
+// Weight fragments are loop-invariant, so hipcc hoists their loads out of the tile loop until it runs
+// out of registers and spills (and ROCm 7.2 miscompiles a partially spilled fragment: the tail dword
+// parked in an AGPR is never copied back).  Where the fragments do not fit, launder the base pointer
+// once per tile so the loads stay inside the loop (they hit L1/L2).  The build rejects any spill.
+template <bool HOIST, typename T> SR_DEV const T* weights_for_tile(const T* w) {
+  if constexpr (!HOIST) {
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    return w + z;
+  } else {
+    return w;
+  }
+}
+
 // 8 consecutive elements from an LDS image (16-byte aligned element offset)
 template <typename T> SR_DEV typename FragOf<T>::type lds_chunk(const T* img, int elem_off) {
   return *reinterpret_cast<const typename FragOf<T>::type*>(img + elem_off);
@@ -105,3 +119,32 @@ SR_DEV bf16x8 lds_tr_frag(const __bf16* img, int rowaddr_lo, int rowaddr_hi) {
 template <typename T> SR_DEV T relu(T x) { return x > (T)0 ? x : (T)0; }
 
 #define SR_HIP_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+// Transposed fragment for a pixel-contraction (weight-gradient) product: element j of lane (r,hh) =
+// img[rowbase(p_j) + r] with p_j = 16 s + 8 (j>>2) + 4 hh + (j&3) (chained order), i.e. this lane's
+// channel r for 8 pixel rows.  bf16: two ds_read_b64_tr_b16 (EXEC must be all ones); fp32: 8 ds_read_b32.
+template <typename T, typename RowBase>
+SR_DEV typename FragOf<T>::type tr_frag(const T* img, int s, int lane, RowBase rowbase) {
+  typename FragOf<T>::type f;
+  const int hh = lane >> 5;
+  if constexpr (sizeof(T) == 2) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int q = (lane >> 2) & 3, p = lane & 3, grp = (lane >> 4) & 1;
+    const int plo = 16 * s + 4 * hh + q;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + rowbase(plo) + 16 * grp + 4 * p));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + rowbase(plo + 8) + 16 * grp + 4 * p));
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  } else {
+    const int r = lane & 31;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = img[rowbase(16 * s + 8 * (j >> 2) + 4 * hh + (j & 3)) + r];
+  }
+  return f;
+}
+
+// accumulator tile -> [reg i][lane] floats in an LDS slab (atomic add: several waves share the slab)
+SR_DEV void slab_add_tile(float* slab, int tile, const f32x16& acc, int lane) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) atomicAdd(slab + (tile * 16 + i) * 64 + lane, acc[i]);
+}

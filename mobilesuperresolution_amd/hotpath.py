@@ -1,0 +1,97 @@
+"""Thin host layer over the C ABI: packs parameters into MFMA fragment blobs (one torch gather per
+layer family) and enqueues the HIP kernels on torch's current stream.  No arithmetic of the SR path
+happens in PyTorch here; torch is used for device memory, streams and the gather/sum plumbing."""
+from __future__ import annotations
+
+import ctypes
+from functools import lru_cache
+from typing import Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import packing as P
+
+
+def block_dims(F: int) -> Tuple[int, int, int]:
+    """(F, E, L) of the reference Block: expand 6, linear 0.84 (models/basic_wdsr_b.py:105-106)."""
+    return F, int(F * 6), int(F * 0.84)
+
+
+@lru_cache(maxsize=None)
+def _dev_tables(F: int, device_index: int):
+    f, e, l = block_dims(F)
+    tab = P.block_tables(f, e, l)
+    gt = P.block_grad_tables(f, e, l)
+    dev = torch.device("cuda", device_index)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    g = tab["geom"]
+    o = g.off
+    # canonical gradient vector order = w1 | w2 | w3 | b1 | b2 | b3 (src layout without constants)
+    E_, L_ = g.E, g.L
+    n_w1, n_w2, n_w3 = E_ * f, L_ * E_, f * L_ * 9
+    ga, gb = gt["a"], gt["b"]
+    # slab A order: w1, w2, b1, b2 ; slab B order: w3, b3  -> positions inside cat(slabA, slabB)
+    a_w1, a_w2 = ga[:n_w1], ga[n_w1:n_w1 + n_w2]
+    a_b1, a_b2 = ga[n_w1 + n_w2:n_w1 + n_w2 + E_], ga[n_w1 + n_w2 + E_:]
+    b_w3, b_b3 = gb[:n_w3] + gt["a_size"], gb[n_w3:] + gt["a_size"]
+    grad_idx = np.concatenate([a_w1, a_w2, b_w3, a_b1, a_b2, b_b3])
+    assert grad_idx.size == o["zero"]
+    return dict(w=t(tab["w"]), cinit=t(tab["cinit"]), grad=t(grad_idx), geom=g, nfrag=tab["nfrag"],
+                slab_a=gt["a_size"], slab_b=gt["b_size"], src_size=o["size"])
+
+
+def tables(F: int, device: torch.device):
+    return _dev_tables(F, device.index if device.index is not None else torch.cuda.current_device())
+
+
+def block_src(w1: torch.Tensor, w2: torch.Tensor, w3: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor,
+              b3: torch.Tensor) -> torch.Tensor:
+    """Canonical per-block source vectors [NB, S] from stacked effective weights/biases
+    (w1 [NB,E,F], w2 [NB,L,E], w3 [NB,F,L,3,3], b* [NB,...]); differentiable."""
+    nb = w1.shape[0]
+    const = w1.new_tensor([0.0, 1.0]).expand(nb, 2)
+    return torch.cat([w1.reshape(nb, -1), w2.reshape(nb, -1), w3.reshape(nb, -1), b1, b2, b3, const], dim=1)
+
+
+def pack_blocks(src_all: torch.Tensor, F: int, dtype: torch.dtype):
+    """src_all [NB, S] fp32 -> (blob [NB, nfrag*512] dtype, cinit [NB, C] fp32)."""
+    tb = tables(F, src_all.device)
+    assert src_all.shape[1] == tb["src_size"], (src_all.shape, tb["src_size"])
+    s = src_all.detach().float()
+    blob = s.index_select(1, tb["w"]).to(dtype).contiguous()
+    cinit = s.index_select(1, tb["cinit"]).contiguous()
+    return blob, cinit
+
+
+def block_fwd(x: torch.Tensor, y: torch.Tensor, blob_i: torch.Tensor, cinit_i: torch.Tensor):
+    n, h, w, f = x.shape
+    L.check(L.lib().sr_wdsr_block_fwd(L.ptr(x), L.ptr(y), L.ptr(blob_i), L.ptr(cinit_i), n, h, w, f,
+                                      L.DTYPE_CODE[x.dtype], L.stream_ptr()), "sr_wdsr_block_fwd")
+
+
+def block_bwd_data(x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, blob_i: torch.Tensor,
+                   cinit_i: torch.Tensor):
+    n, h, w, f = x.shape
+    L.check(L.lib().sr_wdsr_block_bwd_data(L.ptr(x), L.ptr(dy), L.ptr(dx), L.ptr(blob_i), L.ptr(cinit_i),
+                                           n, h, w, f, L.DTYPE_CODE[x.dtype], L.stream_ptr()),
+            "sr_wdsr_block_bwd_data")
+
+
+def block_wgrad(xs: torch.Tensor, dys: torch.Tensor, blob: torch.Tensor, cinit: torch.Tensor,
+                wgs_per_layer: int = 16) -> torch.Tensor:
+    """xs, dys: [NB, N, H, W, F] (block inputs / output gradients); blob [NB, .], cinit [NB, .].
+    Returns d_src [NB, S] (zeros at the two constant slots), fp32."""
+    nb, n, h, w, f = xs.shape
+    tb = tables(f, xs.device)
+    pa = torch.empty((nb, wgs_per_layer, tb["slab_a"]), dtype=torch.float32, device=xs.device)
+    pb = torch.empty((nb, wgs_per_layer, tb["slab_b"]), dtype=torch.float32, device=xs.device)
+    assert xs.is_contiguous() and dys.is_contiguous() and blob.is_contiguous() and cinit.is_contiguous()
+    L.check(L.lib().sr_wdsr_block_wgrad(L.ptr(xs), L.ptr(dys), L.ptr(blob), L.ptr(cinit), L.ptr(pa), L.ptr(pb),
+                                        nb, wgs_per_layer, n, h, w, f, L.DTYPE_CODE[xs.dtype],
+                                        xs.stride(0), dys.stride(0), blob.stride(0), cinit.stride(0),
+                                        L.stream_ptr()), "sr_wdsr_block_wgrad")
+    slab = torch.cat([pa.sum(1), pb.sum(1)], dim=1)
+    g = slab.index_select(1, tb["grad"])
+    return torch.cat([g, g.new_zeros(nb, 2)], dim=1)

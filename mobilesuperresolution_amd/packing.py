@@ -171,3 +171,228 @@ def block_fwd_tables(F: int, E: int, L: int):
             rows[ee < E] = o["b1"] + ee[ee < E]
             cin.append(cinit_index(rows, Z))
     return dict(w=w, cinit=np.concatenate(cin), n_w1=g.NET * g.KS1, n_w2=g.KS2, n_w3=g.KS3, geom=g)
+
+
+@lru_cache(maxsize=None)
+def block_tables(F: int, E: int, L: int):
+    """Tables for all residual-block kernels (forward, backward-data, weight-gradient).
+
+    Blob sections (in 512-element fragments), forward first so wdsr_block_fwd_kernel's offsets hold:
+      W1 | W2 | W3 | W3T | W2T | W1T | ID | W2N
+    C-init floats: b2c[32] | b1c[NET][32] (only when b1 is not folded) | b1n[NET*32] (same condition).
+    """
+    fwd = block_fwd_tables(F, E, L)
+    g = fwd["geom"]
+    o = g.off
+    Z, ONE = o["zero"], o["one"]
+    KS3B = (9 * g.FC + 1) // 2
+    KSI = (g.FC + 1) // 2
+
+    # W3T as A operand of dt^T[l, px] = sum_{u, f} W3[f, l, 8-u] dy[px + u - 1, f]: rows l, chunk q = 2s+hh
+    # -> read offset u = q // FC (row-major 3x3 into the halo'd dy tile), channels f = 8 (q % FC) + j.
+    s, r, hh, j = _grid(KS3B)
+    q = 2 * s + hh
+    u, c = q // g.FC, q % g.FC
+    f = 8 * c + j
+    w3t = _sel((q < 9 * g.FC) & (r < L),
+               o["w3"] + (np.minimum(f, F - 1) * L + np.minimum(r, L - 1)) * 9 + (8 - np.minimum(u, 8)), Z)
+
+    # W2T as A operand of dh^T[e, px] = sum_l W2[l, e] dt^T[l, px]: rows e (tile et), k = l chained (2 k-steps)
+    s, r, hh, j = _grid(g.NET * 2)
+    et, ks = s // 2, s % 2
+    e = 32 * et + r
+    l = k_chained(ks, hh, j)
+    w2t = _sel((e < E) & (l < L), o["w2"] + np.minimum(l, L - 1) * E + np.minimum(e, E - 1), Z)
+
+    # W1T as A operand of dx^T[f, px] += sum_e W1[e, f] dpre^T[e, px]: rows f, k = e chained (k-step 2et+s)
+    s, r, hh, j = _grid(g.KS2)
+    e = k_chained(s, hh, j)
+    w1t = _sel((r < F) & (e < E), o["w1"] + np.minimum(e, E - 1) * F + np.minimum(r, F - 1), Z)
+
+    # identity over the FC chunks of dy (gradient of the skip connection)
+    s, r, hh, j = _grid(KSI)
+    q = 2 * s + hh
+    ident = _sel((q < g.FC) & (r < F) & (8 * q + j == r), ONE, Z)
+
+    # W2N as B operand of dh[px, e] = sum_l dt[px, l] W2[l, e]: columns e (tile et), k = l natural
+    s, r, hh, j = _grid(g.NET * 2)
+    et, ks = s // 2, s % 2
+    e = 32 * et + r
+    l = k_natural(ks, hh, j)
+    w2n = _sel((e < E) & (l < L), o["w2"] + np.minimum(l, L - 1) * E + np.minimum(e, E - 1), Z)
+
+    w = np.concatenate([fwd["w"]] + [a.reshape(-1) for a in (w3t, w2t, w1t, ident, w2n)])
+    cin = [fwd["cinit"]]
+    if not g.fold_b1:
+        ee = np.arange(g.NET * 32)
+        cin.append(np.where(ee < E, o["b1"] + np.minimum(ee, E - 1), Z))
+    sec, off = {}, 0
+    for name, n in (("W1", g.NET * g.KS1), ("W2", g.KS2), ("W3", g.KS3), ("W3T", KS3B), ("W2T", g.NET * 2),
+                    ("W1T", g.KS2), ("ID", KSI), ("W2N", g.NET * 2)):
+        sec[name] = off
+        off += n
+    assert off * 512 == w.size
+    return dict(w=w, cinit=np.concatenate(cin), sec=sec, nfrag=off, geom=g, KS3B=KS3B, KSI=KSI)
+
+
+# ---- accumulator-layout slabs written by the weight-gradient kernels -> canonical gradients ----
+def _acc_pos(tile, row, col):
+    """offset of element (row, col) of 32x32 accumulator tile #tile in a [tile][reg 16][lane 64] slab
+    (lane-contiguous so the in-workgroup LDS reduction is bank-conflict free)"""
+    hh = (row >> 2) & 1
+    i = (row & 3) + 4 * (row >> 3)
+    return (tile * 16 + i) * 64 + col + 32 * hh
+
+
+@lru_cache(maxsize=None)
+def block_grad_tables(F: int, E: int, L: int):
+    """Gather tables: canonical gradient vector (same layout as BlockGeom.off, without the two
+    constants) = slab[idx].  Slab A (wgrad12): dW1T tiles [f rows, e cols] x NET, then dW2 tiles
+    [l rows, e cols] x NET, then db1[NET*32], db2[32].  Slab B (wgrad3): 9 tiles [l rows, f cols]
+    indexed by read offset u (tap = 8 - u); the ones channel l = L at the centre carries db3."""
+    g = BlockGeom(F, E, L)
+    NET = g.NET
+    e, f = np.meshgrid(np.arange(E), np.arange(F), indexing="ij")
+    w1 = _acc_pos(e // 32, f, e % 32)
+    l, e2 = np.meshgrid(np.arange(L), np.arange(E), indexing="ij")
+    w2 = _acc_pos(NET + e2 // 32, l, e2 % 32)
+    base = 2 * NET * 1024
+    b1 = base + np.arange(E)
+    b2 = base + NET * 32 + np.arange(L)
+    slab_a = base + NET * 32 + 32
+    f3, l3, tap = np.meshgrid(np.arange(F), np.arange(L), np.arange(9), indexing="ij")
+    w3 = _acc_pos(8 - tap, l3, f3)
+    b3 = _acc_pos(np.full(F, 4), np.full(F, L), np.arange(F))
+    return dict(a=np.concatenate([w1.reshape(-1), w2.reshape(-1), b1, b2]), a_size=slab_a,
+                a_order=("w1", "w2", "b1", "b2"),
+                b=np.concatenate([w3.reshape(-1), b3]), b_size=9 * 1024, b_order=("w3", "b3"), geom=g)
+
+
+# =====================================================================================
+# head (3x3, 3 -> F) and tail (3x3 F -> 3r^2) + skip (5x5, 3 -> 3r^2) + PixelShuffle(r)
+# reference: models/basic_wdsr_b.py:32-42 (head), :55-64 (tail), :66-78 (skip), :80-92 (shuffle, mean)
+# =====================================================================================
+# The LR image is staged in LDS as [pixel][4]: 3 colours minus the mean, and a ones channel that
+# carries the bias.  A fragment chunk (8 elements) is two horizontally adjacent pixels.
+
+@dataclass(frozen=True)
+class EndsGeom:
+    F: int
+    R: int                      # upscale factor
+
+    @property
+    def CO(self):               # conv channels before the shuffle
+        return 3 * self.R * self.R
+
+    @property
+    def NT(self):
+        return (self.CO + 31) // 32
+
+    @property
+    def COP(self):              # dconv channels held in LDS
+        return (self.CO + 7) // 8 * 8
+
+    @property
+    def CC(self):
+        return self.COP // 8
+
+    @property
+    def FC(self):
+        return self.F // 8
+
+    @property
+    def KST(self):              # k-steps of the fused tail+skip product
+        return (9 * self.FC + 15 + 1) // 2
+
+    @property
+    def KSTB(self):             # k-steps of tail backward-data
+        return (9 * self.CC + 1) // 2
+
+    @property
+    def tail_off(self):         # canonical tail source: wt | ws | btot | 0 | 1
+        CO, F = self.CO, self.F
+        o, d = 0, {}
+        for name, n in (("wt", CO * F * 9), ("ws", CO * 3 * 25), ("b", CO), ("zero", 1), ("one", 1)):
+            d[name] = o
+            o += n
+        d["size"] = o
+        return d
+
+    @property
+    def head_off(self):         # canonical head source: wh | bh | 0 | 1
+        F = self.F
+        return {"wh": 0, "b": F * 27, "zero": F * 27 + F, "one": F * 27 + F + 1, "size": F * 27 + F + 2}
+
+
+@lru_cache(maxsize=None)
+def ends_tables(F: int, R: int):
+    g = EndsGeom(F, R)
+    CO, FC, CC = g.CO, g.FC, g.CC
+    ot, oh = g.tail_off, g.head_off
+
+    # ---- head: rows f, chunks q = 2s+hh < 6: ky = q//2, m = q%2 -> kx = 2m + (j>>2), ci = j&3 ----
+    s, r, hh, j = _grid(3)
+    q = 2 * s + hh
+    ky, m = q // 2, q % 2
+    kx, ci = 2 * m + (j >> 2), j & 3
+    ok = (r < F) & (kx < 3)
+    rf = np.minimum(r, F - 1)
+    head = np.full(s.shape, oh["zero"], dtype=np.int64)
+    head = _sel(ok & (ci < 3), oh["wh"] + ((rf * 3 + np.minimum(ci, 2)) * 3 + ky) * 3 + np.minimum(kx, 2), head)
+    head = _sel(ok & (ci == 3) & (ky == 1) & (kx == 1), oh["b"] + rf, head)
+
+    # ---- tail + skip: rows ch (NT tiles); chunks q < 9 FC: tail (tap, 8 feature channels);
+    #      then 15 image chunks: ky = q'//3, m = q'%3 -> kx = 2m + (j>>2), ci = j&3 ----
+    s, r, hh, j = _grid(g.NT * g.KST)
+    ti, ks = s // g.KST, s % g.KST
+    ch = 32 * ti + r
+    chc = np.minimum(ch, CO - 1)
+    q = 2 * ks + hh
+    tail = np.full(s.shape, ot["zero"], dtype=np.int64)
+    is_t = q < 9 * FC
+    tap, c = q // FC, q % FC
+    f = 8 * c + j
+    tail = _sel(is_t & (ch < CO), ot["wt"] + (chc * F + np.minimum(f, F - 1)) * 9 + np.minimum(tap, 8), tail)
+    qs = q - 9 * FC
+    ky, m = qs // 3, qs % 3
+    kx, ci = 2 * m + (j >> 2), j & 3
+    is_s = (~is_t) & (qs < 15) & (ch < CO) & (kx < 5)
+    tail = _sel(is_s & (ci < 3),
+                ot["ws"] + ((chc * 3 + np.minimum(ci, 2)) * 5 + np.clip(ky, 0, 4)) * 5 + np.minimum(kx, 4), tail)
+    tail = _sel(is_s & (ci == 3) & (ky == 2) & (kx == 2), ot["b"] + chc, tail)
+
+    # ---- tail backward-data: rows f, chunks q < 9 CC: read offset u = q // CC, channels 8 (q%CC)+j;
+    #      dfeat[px, f] = sum_{u, ch} Wt[ch, f, 8-u] dconv[px + u - 1, ch] ----
+    s, r, hh, j = _grid(g.KSTB)
+    q = 2 * s + hh
+    u, c = q // CC, q % CC
+    ch = 8 * c + j
+    tbd = _sel((q < 9 * CC) & (r < F) & (ch < CO),
+               ot["wt"] + (np.minimum(ch, CO - 1) * F + np.minimum(r, F - 1)) * 9 + (8 - np.minimum(u, 8)),
+               ot["zero"])
+
+    tail_w = np.concatenate([tail.reshape(-1), tbd.reshape(-1)])
+    return dict(head=head.reshape(-1), tail=tail_w, geom=g, n_head=3, n_tail=g.NT * g.KST, n_tbd=g.KSTB)
+
+
+@lru_cache(maxsize=None)
+def ends_grad_tables(F: int, R: int):
+    """Gather tables for the slabs of the tail / head weight-gradient kernels.
+    Tail slab: tiles [(tap * NT + ti)] (rows ch, cols f) for the 9 taps, then [(ky * NT + ti)] (rows ch,
+    cols (kx, ci) = 4 kx + ci) for the 5 skip rows.  Head slab: 3 tiles [ky] (rows f, cols 4 kx + ci).
+    The bias is the ones-channel column at the centre tap."""
+    g = EndsGeom(F, R)
+    CO, NT = g.CO, g.NT
+    ch, f, tap = np.meshgrid(np.arange(CO), np.arange(F), np.arange(9), indexing="ij")
+    wt = _acc_pos(tap * NT + ch // 32, ch % 32, f)
+    base = 9 * NT
+    ch, ci, ky, kx = np.meshgrid(np.arange(CO), np.arange(3), np.arange(5), np.arange(5), indexing="ij")
+    ws = _acc_pos(base + ky * NT + ch // 32, ch % 32, 4 * kx + ci)
+    chb = np.arange(CO)
+    bt = _acc_pos(base + 2 * NT + chb // 32, chb % 32, 4 * 2 + 3)
+    tail = np.concatenate([wt.reshape(-1), ws.reshape(-1), bt])
+    fh, ci, ky, kx = np.meshgrid(np.arange(F), np.arange(3), np.arange(3), np.arange(3), indexing="ij")
+    wh = _acc_pos(ky, fh, 4 * kx + ci)
+    bh = _acc_pos(np.full(F, 1), np.arange(F), np.full(F, 4 * 1 + 3))
+    head = np.concatenate([wh.reshape(-1), bh])
+    return dict(tail=tail, tail_size=(9 * NT + 5 * NT) * 1024, head=head, head_size=3 * 1024, geom=g)

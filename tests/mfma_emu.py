@@ -110,3 +110,193 @@ def emu_block_fwd(x_nhwc, packed_w, cinit_tab, geom, dtype="f32", TH=12, TW=24):
                             for jj in range(4):
                                 y[Y, X, gq * 8 + HH[l] * 4 + jj] = oacc[l, 4 * gq + jj]
     return rnd(y, dtype)
+
+
+# =====================================================================================
+# backward of the residual block
+# =====================================================================================
+def _kch(s, hh, j):
+    return 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3)
+
+
+def _stage_bwd(x_nhwc, dy_nhwc, g, ty0, tx0, TH, TW, dtype):
+    """LDS images of the backward kernels: dy with a 1-pixel halo [NPXH_PAD(+pad)][F] and the core x
+    tile [TH*TW][KX] (ones channel at F when b1 is folded).  Returned flat with row strides F / KX."""
+    H, W, F = x_nhwc.shape
+    HW_, HH_ = TW + 2, TH + 2
+    NPXH_PAD = (HW_ * HH_ + 31) // 32 * 32
+    DY = np.zeros((NPXH_PAD + 2, F))
+    for hp in range(HW_ * HH_):
+        Y, X = ty0 - 1 + hp // HW_, tx0 - 1 + hp % HW_
+        if 0 <= Y < H and 0 <= X < W:
+            DY[hp] = dy_nhwc[Y, X]
+    XC = np.zeros((TH * TW + 1, g.KX))
+    valid = np.zeros(TH * TW, dtype=bool)
+    for pc in range(TH * TW):
+        Y, X = ty0 + pc // TW, tx0 + pc % TW
+        if Y < H and X < W:
+            XC[pc, :F] = x_nhwc[Y, X]
+            valid[pc] = True
+    if g.fold_b1:
+        XC[:, F] = 1.0
+    return rnd(DY, dtype).reshape(-1), rnd(XC, dtype).reshape(-1), valid
+
+
+def _chunk(flat, base_elem):
+    """(64, 8) fragment: 8 consecutive elements starting at per-lane element offsets"""
+    return np.stack([flat[base_elem + j] for j in range(8)], 1)
+
+
+def _dt_tile(DY, pw, sec, tab, g, hbase, HW_):
+    F, FC = g.F, g.FC
+    dtacc = np.zeros((64, 16))
+    for s in range(tab["KS3B"]):
+        q = 2 * s + HH
+        u, c = q // FC, q % FC
+        off = np.where(q < 9 * FC, (hbase + (u // 3) * HW_ + u % 3) * F + c * 8, hbase * F)
+        dtacc = mma16(wfrag(pw, sec["W3T"] + s), _chunk(DY, off), dtacc)
+    return dtacc
+
+
+def emu_block_bwd_data(x_nhwc, dy_nhwc, packed_w, cinit_tab, tab, dtype="f32", TH=12, TW=24):
+    """Mirror of wdsr_block_bwd_data_kernel: dx = dy + W1^T [relu'(h) * (W2^T conv3x3^T(dy))]."""
+    g, sec = tab["geom"], tab["sec"]
+    H, W, F = x_nhwc.shape
+    HW_ = TW + 2
+    pw = rnd(packed_w, dtype)
+    dx = np.zeros((H, W, F))
+    for ty0 in range(0, H, TH):
+        for tx0 in range(0, W, TW):
+            DY, XC, _ = _stage_bwd(x_nhwc, dy_nhwc, g, ty0, tx0, TH, TW, dtype)
+            for ot in range((TH // 4) * (TW // 8)):
+                oy = (ot // (TW // 8)) * 4 + (R >> 3)
+                ox = (ot % (TW // 8)) * 8 + (R & 7)
+                hbase, pc = oy * HW_ + ox, oy * TW + ox
+                dtacc = _dt_tile(DY, pw, sec, tab, g, hbase, HW_)
+                dtb = [acc_to_frag(dtacc, s, dtype) for s in range(2)]
+                xb = [_chunk(XC, pc * g.KX + (2 * s + HH) * 8) for s in range(g.KS1)]
+                dxacc = np.zeros((64, 16))
+                for et in range(g.NET):
+                    hacc = np.zeros((64, 16)) if g.fold_b1 else cinit(cinit_tab[32 + 32 * et:64 + 32 * et])
+                    for s in range(g.KS1):
+                        hacc = mma16(wfrag(pw, sec["W1"] + et * g.KS1 + s), xb[s], hacc)
+                    dh = np.zeros((64, 16))
+                    for s in range(2):
+                        dh = mma16(wfrag(pw, sec["W2T"] + 2 * et + s), dtb[s], dh)
+                    dpre = np.where(hacc > 0, dh, 0.0)
+                    for s in range(2):
+                        if 2 * et + s < g.KS2:
+                            dxacc = mma16(wfrag(pw, sec["W1T"] + 2 * et + s), acc_to_frag(dpre, s, dtype), dxacc)
+                for s in range(tab["KSI"]):
+                    q = 2 * s + HH
+                    c = np.where(q < g.FC, q, 0)
+                    dxacc = mma16(wfrag(pw, sec["ID"] + s), _chunk(DY, (hbase + HW_ + 1) * F + c * 8), dxacc)
+                for l in range(64):
+                    Y, X = ty0 + oy[l], tx0 + ox[l]
+                    if Y < H and X < W:
+                        for gq in range(g.FC):
+                            for jj in range(4):
+                                dx[Y, X, gq * 8 + HH[l] * 4 + jj] = dxacc[l, 4 * gq + jj]
+    return rnd(dx, dtype)
+
+
+def _tr_frag(flat, rowbase_of_px, s, ch):
+    """transposed fragment: element j = flat[rowbase(px_j) + ch], px_j = chained order of k-step s"""
+    return np.stack([flat[rowbase_of_px(_kch(s, HH, j)) + ch] for j in range(8)], 1)
+
+
+def emu_block_wgrad12(x_nhwc, dy_nhwc, packed_w, cinit_tab, tab, dtype="f32", TH=12, TW=24, slab=None):
+    """Mirror of wdsr_block_wgrad12_kernel for one image; returns slab A (float64), accumulating
+    into `slab` when given.  Layout: packing.block_grad_tables."""
+    g, sec = tab["geom"], tab["sec"]
+    H, W, F = x_nhwc.shape
+    HW_ = TW + 2
+    NET = g.NET
+    pw = rnd(packed_w, dtype)
+    dW1T = [np.zeros((64, 16)) for _ in range(NET)]
+    dW2 = [np.zeros((64, 16)) for _ in range(NET)]
+    db1 = np.zeros((NET, 64))
+    db2acc = np.zeros((64, 16))
+    for ty0 in range(0, H, TH):
+        for tx0 in range(0, W, TW):
+            DY, XC, valid = _stage_bwd(x_nhwc, dy_nhwc, g, ty0, tx0, TH, TW, dtype)
+            for ot in range((TH // 4) * (TW // 8)):
+                toy, tox = (ot // (TW // 8)) * 4, (ot % (TW // 8)) * 8
+                oy, ox = toy + (R >> 3), tox + (R & 7)
+                hbase, pc = oy * HW_ + ox, oy * TW + ox
+                dtacc = _dt_tile(DY, pw, sec, tab, g, hbase, HW_)
+                dtacc = np.where(valid[pc][:, None], dtacc, 0.0)
+                db2acc += dtacc
+                DT = np.zeros((33, 32))
+                for gq in range(4):
+                    for jj in range(4):
+                        DT[R, gq * 8 + HH * 4 + jj] = rnd(dtacc[:, 4 * gq + jj], dtype)
+                DT = DT.reshape(-1)
+                dtA = [_chunk(DT, R * 32 + (2 * s + HH) * 8) for s in range(2)]
+                dtT = [_tr_frag(DT, lambda p: p * 32, s, R) for s in range(2)]
+                xA = [_chunk(XC, pc * g.KX + (2 * s + HH) * 8) for s in range(g.KS1)]
+                pcof = lambda p: ((toy + (p >> 3)) * TW + tox + (p & 7)) * g.KX
+                xT = [_tr_frag(XC, pcof, s, R) for s in range(2)]
+                for et in range(NET):
+                    if g.fold_b1:
+                        h2 = np.zeros((64, 16))
+                    else:
+                        h2 = np.repeat(np.asarray(cinit_tab, dtype=np.float64)[32 + NET * 32 + 32 * et + R][:, None], 16, 1)
+                    for s in range(g.KS1):
+                        h2 = mma16(xA[s], wfrag(pw, sec["W1"] + et * g.KS1 + s), h2)
+                    dh2 = np.zeros((64, 16))
+                    for s in range(2):
+                        dh2 = mma16(dtA[s], wfrag(pw, sec["W2N"] + 2 * et + s), dh2)
+                    dpre2 = np.where(h2 > 0, dh2, 0.0)
+                    h2r = np.maximum(h2, 0.0)
+                    db1[et] += dpre2.sum(1)
+                    for s in range(2):
+                        dW1T[et] = mma16(xT[s], acc_to_frag(dpre2, s, dtype), dW1T[et])
+                        dW2[et] = mma16(dtT[s], acc_to_frag(h2r, s, dtype), dW2[et])
+    out = np.concatenate([a.T.reshape(-1) for a in dW1T] + [a.T.reshape(-1) for a in dW2])   # [tile][reg][lane]
+    b1 = (db1[:, :32] + db1[:, 32:]).reshape(-1)
+    b2 = np.zeros(32)
+    for i in range(16):
+        for hh in range(2):
+            b2[(i & 3) + 8 * (i >> 2) + 4 * hh] = db2acc[HH == hh, i].sum()
+    out = np.concatenate([out, b1, b2])
+    return out if slab is None else slab + out
+
+
+def emu_block_wgrad3(x_nhwc, dy_nhwc, packed_w, cinit_tab, tab, dtype="f32", TH=12, TW=24, slab=None):
+    """Mirror of wdsr_block_wgrad3_kernel for one image; returns slab B (9 raw accumulator tiles)."""
+    g, sec = tab["geom"], tab["sec"]
+    H, W, F = x_nhwc.shape
+    HW_ = TW + 2
+    pw = rnd(packed_w, dtype)
+    dW3T = [np.zeros((64, 16)) for _ in range(9)]
+    for ty0 in range(0, H, TH):
+        for tx0 in range(0, W, TW):
+            DY, XC, valid = _stage_bwd(x_nhwc, dy_nhwc, g, ty0, tx0, TH, TW, dtype)
+            for ot in range((TH // 4) * (TW // 8)):
+                toy, tox = (ot // (TW // 8)) * 4, (ot % (TW // 8)) * 8
+                oy, ox = toy + (R >> 3), tox + (R & 7)
+                pc = oy * TW + ox
+                xb = [_chunk(XC, pc * g.KX + (2 * s + HH) * 8) for s in range(g.KS1)]
+                tacc = cinit(cinit_tab[0:32])
+                for et in range(g.NET):
+                    hacc = np.zeros((64, 16)) if g.fold_b1 else cinit(cinit_tab[32 + 32 * et:64 + 32 * et])
+                    for s in range(g.KS1):
+                        hacc = mma16(wfrag(pw, sec["W1"] + et * g.KS1 + s), xb[s], hacc)
+                    hacc = np.maximum(hacc, 0)
+                    for s in range(2):
+                        if 2 * et + s < g.KS2:
+                            tacc = mma16(wfrag(pw, sec["W2"] + 2 * et + s), acc_to_frag(hacc, s, dtype), tacc)
+                tacc = np.where(valid[pc][:, None], tacc, 0.0)
+                TS = np.zeros((33, 32))
+                for gq in range(4):
+                    for jj in range(4):
+                        TS[R, gq * 8 + HH * 4 + jj] = rnd(tacc[:, 4 * gq + jj], dtype)
+                TS = TS.reshape(-1)
+                tT = [_tr_frag(TS, lambda p: p * 32, s, R) for s in range(2)]
+                for u in range(9):
+                    hof = lambda p, u=u: ((toy + (p >> 3) + u // 3) * HW_ + tox + (p & 7) + u % 3) * F
+                    for s in range(2):
+                        dW3T[u] = mma16(tT[s], _tr_frag(DY, hof, s, R), dW3T[u])
+    out = np.concatenate([a.T.reshape(-1) for a in dW3T])          # [tile][reg][lane]
+    return out if slab is None else slab + out

@@ -78,3 +78,92 @@ def test_block_fwd_48x48_batch_vs_oracle():
     y = run_block_fwd(x, block_src(d), f, torch.float32)
     assert not torch.isnan(y).any()
     assert (y - exp).abs().max().item() <= 1e-5 * exp.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------
+# backward
+# ------------------------------------------------------------------------------------------
+def _src_with_grad(d):
+    ps = {k[2:]: v.clone().requires_grad_(True) for k, v in d.items() if k.startswith("p/")}
+    w = [O.weight_norm(ps[f"body.{i}.weight_v"], ps[f"body.{i}.weight_g"]).reshape(-1) for i in (0, 2, 3)]
+    b = [ps[f"body.{i}.bias"] for i in (0, 2, 3)]
+    return torch.cat(w + b + [torch.tensor([0.0, 1.0])]), ps
+
+
+def run_block_bwd(d, f, dtype, wgs=3):
+    from mobilesuperresolution_amd import hotpath as HP
+    src, ps = _src_with_grad(d)
+    srcd = src.detach().cuda()[None]
+    blob, cinit = HP.pack_blocks(srcd, f, dtype)
+    x = d["x"].cuda().permute(0, 2, 3, 1).contiguous().to(dtype)
+    dy = d["dy"].cuda().permute(0, 2, 3, 1).contiguous().to(dtype)
+    dx = torch.full_like(x, float("nan"))
+    HP.block_bwd_data(x, dy, dx, blob[0], cinit[0])
+    dsrc = HP.block_wgrad(x[None], dy[None], blob, cinit, wgs_per_layer=wgs)
+    torch.cuda.synchronize()
+    src.backward(dsrc[0].cpu())
+    return dx.float().permute(0, 3, 1, 2).cpu(), {k: p.grad for k, p in ps.items()}
+
+
+@pytest.mark.parametrize("f", [24, 32])
+def test_block_bwd_fp32_matches_reference_golden(golden_dir, f):
+    d = _load(golden_dir, f"g2_block_f{f}.npz")
+    dx, grads = run_block_bwd(d, f, torch.float32)
+    err = (dx - d["dx"]).abs().max().item() / d["dx"].abs().max().item()
+    print(f"\nF={f} fp32 dx rel err {err:.2e}")
+    assert err <= 1e-5
+    for k, g in grads.items():
+        exp = d["g/" + k]
+        e = (g - exp).abs().max().item() / exp.abs().max().item()
+        print(f"  {k}: rel err {e:.2e}")
+        assert e <= 1e-4, k
+
+
+def _effective(d, f, rnd):
+    """effective (weight-normalised) weights/biases of the golden block, optionally bf16-rounded"""
+    q = (lambda t: t.bfloat16().float()) if rnd else (lambda t: t)
+    w = [q(O.weight_norm(d[f"p/body.{i}.weight_v"], d[f"p/body.{i}.weight_g"])) for i in (0, 2, 3)]
+    b = [q(d[f"p/body.{i}.bias"]) for i in (0, 2, 3)]
+    return [t.clone().requires_grad_(True) for t in w + b]
+
+
+def _block_eff(x, p):
+    import torch.nn.functional as Fn
+    h = Fn.relu(Fn.conv2d(x, p[0], p[3]))
+    t = Fn.conv2d(h, p[1], p[4])
+    return Fn.conv2d(t, p[2], p[5], padding=1) + x
+
+
+@pytest.mark.parametrize("f", [24, 32])
+def test_block_bwd_bf16_tolerance(golden_dir, f):
+    """bf16 storage / bf16 MFMA operands, fp32 accumulate.  The oracle gets the same bf16-rounded
+    x, dy and effective weights, so the ReLU masks agree and what remains is the rounding of the
+    intermediates (h, t, dt, dpre to bf16): tolerance 2% of each tensor's max, relative L2 <= 1%."""
+    from mobilesuperresolution_amd import hotpath as HP
+    d = _load(golden_dir, f"g2_block_f{f}.npz")
+    p = _effective(d, f, True)
+    x = d["x"].bfloat16().float().requires_grad_(True)
+    dy = d["dy"].bfloat16().float()
+    _block_eff(x, p).backward(dy)
+    src = torch.cat([t.detach().reshape(-1) for t in p] + [torch.tensor([0.0, 1.0])]).cuda()[None]
+    blob, cinit = HP.pack_blocks(src, f, torch.bfloat16)
+    xd = x.detach().cuda().permute(0, 2, 3, 1).contiguous().bfloat16()
+    dyd = dy.cuda().permute(0, 2, 3, 1).contiguous().bfloat16()
+    dx = torch.full_like(xd, float("nan"))
+    HP.block_bwd_data(xd, dyd, dx, blob[0], cinit[0])
+    dsrc = HP.block_wgrad(xd[None], dyd[None], blob, cinit, wgs_per_layer=5)[0].cpu()
+    got_dx = dx.float().permute(0, 3, 1, 2).cpu()
+
+    def cmp(name, got, exp):
+        mx = (got - exp).abs().max().item() / exp.abs().max().item()
+        l2 = ((got - exp).norm() / exp.norm()).item()
+        print(f"  {name}: max rel {mx:.2e}  L2 rel {l2:.2e}")
+        assert mx <= 2e-2 and l2 <= 1e-2, name
+
+    print(f"\nF={f} bf16 backward")
+    cmp("dx", got_dx, x.grad)
+    o = 0
+    for name, t in zip(("w1", "w2", "w3", "b1", "b2", "b3"), p):
+        n = t.numel()
+        cmp(name, dsrc[o:o + n], t.grad.reshape(-1))
+        o += n

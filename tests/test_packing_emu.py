@@ -57,3 +57,47 @@ def test_geometry_constants():
     assert (g.KX, g.KS1, g.NET, g.KS2, g.LP, g.CPT, g.KS3) == (32, 2, 5, 9, 24, 3, 15)
     g = P.BlockGeom(32, 192, 26)
     assert (g.KX, g.KS1, g.NET, g.KS2, g.LP, g.CPT, g.KS3) == (32, 2, 6, 12, 32, 4, 20)
+
+
+def _oracle_src_with_grad(d):
+    """canonical src vector as a differentiable function of (weight_g, weight_v, bias)"""
+    ps = {k[2:]: v.clone().requires_grad_(True) for k, v in d.items() if k.startswith("p/")}
+    w = [O.weight_norm(ps[f"body.{i}.weight_v"], ps[f"body.{i}.weight_g"]).reshape(-1) for i in (0, 2, 3)]
+    b = [ps[f"body.{i}.bias"] for i in (0, 2, 3)]
+    return torch.cat(w + b + [torch.tensor([0.0, 1.0])]), ps
+
+
+@pytest.mark.parametrize("f", [24, 32])
+def test_block_bwd_tables_match_golden(golden_dir, f):
+    d = _load(golden_dir, f"g2_block_f{f}.npz")
+    tab = P.block_tables(f, 6 * f, int(f * 0.84))
+    gt = P.block_grad_tables(f, 6 * f, int(f * 0.84))
+    g = tab["geom"]
+    src_t, ps = _oracle_src_with_grad(d)
+    src = src_t.detach().double().numpy()
+    pw, ci = src[tab["w"]], src[tab["cinit"]]
+    slab_a, slab_b = None, None
+    for n in range(d["x"].shape[0]):
+        x = d["x"][n].permute(1, 2, 0).double().numpy()
+        dy = d["dy"][n].permute(1, 2, 0).double().numpy()
+        dx = M.emu_block_bwd_data(x, dy, pw, ci, tab)
+        exp = d["dx"][n].permute(1, 2, 0).double().numpy()
+        assert np.abs(dx - exp).max() <= 1e-5 * np.abs(exp).max()
+        slab_a = M.emu_block_wgrad12(x, dy, pw, ci, tab, slab=slab_a)
+        slab_b = M.emu_block_wgrad3(x, dy, pw, ci, tab, slab=slab_b)
+    assert slab_a.size == gt["a_size"] and slab_b.size == gt["b_size"]
+    ga, gb = slab_a[gt["a"]], slab_b[gt["b"]]
+    o = g.off
+    dsrc = np.zeros(o["size"])
+    E, L = g.E, g.L
+    dsrc[o["w1"]:o["w1"] + E * f] = ga[:E * f]
+    dsrc[o["w2"]:o["w2"] + L * E] = ga[E * f:E * f + L * E]
+    dsrc[o["b1"]:o["b1"] + E] = ga[E * f + L * E:E * f + L * E + E]
+    dsrc[o["b2"]:o["b2"] + L] = ga[E * f + L * E + E:]
+    dsrc[o["w3"]:o["w3"] + f * L * 9] = gb[:f * L * 9]
+    dsrc[o["b3"]:o["b3"] + f] = gb[f * L * 9:]
+    src_t.backward(torch.from_numpy(dsrc).float())
+    for k, p in ps.items():
+        exp = d["g/" + k]
+        err = (p.grad - exp).abs().max().item()
+        assert err <= 1e-4 * exp.abs().max().item(), (k, err)
