@@ -58,6 +58,26 @@ int sr_wdsr_block_wgrad(const void* x, const void* dy, const void* wblob, const 
                         long x_ls, long dy_ls, long w_ls, long c_ls, sr_stream_t stream);
 int sr_wdsr_block_slab_sizes(int F, int* slab_a, int* slab_b);
 
+/* Head conv forward.  Replaces `x - image_mean` + self.head(x), models/basic_wdsr_b.py:86-87:
+ * x NCHW fp32 [N,3,H,W] in [0,1] -> y NHWC [N,H,W,F].  wblob: packing.ends_tables()["head"]. */
+int sr_head_fwd(const float* x_nchw, void* y, const void* wblob, float mean, int N, int H, int W, int F,
+                int dtype, sr_stream_t stream);
+/* Fused tail: self.tail(y) + self.skip(x - mean) -> PixelShuffle(R) -> + mean, models/basic_wdsr_b.py:90-92.
+ * feat NHWC [N,H,W,F], x NCHW fp32, out NCHW fp32 [N,3,R*H,R*W].  R in {2,3,4}.
+ * wblob: packing.ends_tables()["tail"] (forward section, then the backward-data section). */
+int sr_tail_fwd(const void* feat, const float* x_nchw, float* out, const void* wblob, float mean,
+                int N, int H, int W, int F, int R, int dtype, sr_stream_t stream);
+/* d(loss)/d(feat) of the tail from d(loss)/d(out) (NCHW fp32, HR). */
+int sr_tail_bwd_data(const float* dout, void* dfeat, const void* wblob, int N, int H, int W, int F, int R,
+                     int dtype, sr_stream_t stream);
+/* Weight/bias gradients of tail + skip: partial[wgs][14*NT*1024] floats in accumulator layout
+ * (packing.ends_grad_tables()["tail"]); NT = ceil(3 R^2 / 32). */
+int sr_tail_wgrad(const float* dout, const void* feat, const float* x_nchw, float mean, float* partial,
+                  int wgs, int N, int H, int W, int F, int R, int dtype, sr_stream_t stream);
+/* Weight/bias gradient of the head conv from dy0 = d(loss)/d(head output), NHWC: partial[wgs][3*1024]. */
+int sr_head_wgrad(const void* dy0, const float* x_nchw, float mean, float* partial, int wgs,
+                  int N, int H, int W, int F, int dtype, sr_stream_t stream);
+
 /* ---- hardware probes used by tests/test_gpu_probe.py (lane maps the kernels rely on) ---- */
 int sr_probe_mfma_bf16(const void* a_frag, const void* b_frag, float* acc_out, sr_stream_t stream);
 int sr_probe_mfma_f32(const float* a_frag, const float* b_frag, float* acc_out, sr_stream_t stream);

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libsr_hotpath.so")
 ABI_VERSION = 1
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
 
-_P, _I, _Z, _L = c_void_p, c_int, c_size_t, ctypes.c_long
+_P, _I, _Z, _L, _F = c_void_p, c_int, c_size_t, ctypes.c_long, ctypes.c_float
 # name -> (argtypes, restype); must list every symbol include/sr_hotpath.h declares
 SIGNATURES = {
     "sr_abi_version": ([], _I),
@@ -21,6 +21,11 @@ SIGNATURES = {
     "sr_wdsr_block_bwd_data": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block_wgrad": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P], _I),
     "sr_wdsr_block_slab_sizes": ([_I, _P, _P], _I),
+    "sr_head_fwd": ([_P, _P, _P, _F, _I, _I, _I, _I, _I, _P], _I),
+    "sr_tail_fwd": ([_P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P], _I),
+    "sr_tail_bwd_data": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
+    "sr_tail_wgrad": ([_P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    "sr_head_wgrad": ([_P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_probe_mfma_bf16": ([_P, _P, _P, _P], _I),
     "sr_probe_mfma_f32": ([_P, _P, _P, _P], _I),
     "sr_probe_tr_read": ([_P, _I, _P, _P, _P], _I),

@@ -1,6 +1,7 @@
 // C-ABI entry points of libsr_hotpath.so (declared in include/sr_hotpath.h).
 #include "../../include/sr_hotpath.h"
 #include "wdsr_block.h"
+#include "wdsr_ends.h"
 
 extern "C" int sr_abi_version(void) { return 1; }
 
@@ -92,6 +93,90 @@ extern "C" int sr_wdsr_block_fwd(const void* x, void* y, const void* wblob, cons
   if (F == 32 && dtype == SR_DTYPE_BF16) return launch_block_fwd<__bf16, 32, 192, 26>(x, y, wblob, cinit, N, H, W, st);
   if (F == 32 && dtype == SR_DTYPE_F32) return launch_block_fwd<float, 32, 192, 26>(x, y, wblob, cinit, N, H, W, st);
   return -1;
+}
+
+// ------------------------------------------------------------------------------------------
+// head / tail
+// ------------------------------------------------------------------------------------------
+namespace {
+template <typename E> dim3 tile_grid(int N, int H, int W, int* tiles_x) {
+  *tiles_x = (W + E::TW - 1) / E::TW;
+  return dim3(*tiles_x * ((H + E::TH - 1) / E::TH), N);
+}
+#define SR_DISPATCH_TF(CALL)                                                     \
+  if (F == 24 && dtype == SR_DTYPE_BF16) { CALL(__bf16, 24) }                    \
+  else if (F == 24 && dtype == SR_DTYPE_F32) { CALL(float, 24) }                 \
+  else if (F == 32 && dtype == SR_DTYPE_BF16) { CALL(__bf16, 32) }               \
+  else if (F == 32 && dtype == SR_DTYPE_F32) { CALL(float, 32) }                 \
+  else return -1;
+#define SR_DISPATCH_R(CALL, T, F_)                                               \
+  if (R == 4) { CALL(T, F_, 4) } else if (R == 2) { CALL(T, F_, 2) } else if (R == 3) { CALL(T, F_, 3) } else return -1;
+}  // namespace
+
+extern "C" int sr_head_fwd(const float* x, void* y, const void* wblob, float mean, int N, int H, int W, int F,
+                           int dtype, sr_stream_t stream) {
+  if (!x || !y || !wblob || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(T, F_) { typedef EndsCfg<F_, 4> E; int tx; dim3 g = tile_grid<E>(N, H, W, &tx); \
+    hipLaunchKernelGGL((sr_head_fwd_kernel<T, F_>), g, dim3(256), 0, st, x, (T*)y, (const T*)wblob, mean, H, W, tx); }
+  SR_DISPATCH_TF(CALL)
+#undef CALL
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sr_tail_fwd(const void* feat, const float* x, float* out, const void* wblob, float mean, int N,
+                           int H, int W, int F, int R, int dtype, sr_stream_t stream) {
+  if (!feat || !x || !out || !wblob || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
+  hipStream_t st = (hipStream_t)stream;
+#define CALLR(T, F_, R_) { typedef EndsCfg<F_, R_> E; int tx; dim3 g = tile_grid<E>(N, H, W, &tx); \
+    hipLaunchKernelGGL((sr_tail_fwd_kernel<T, F_, R_>), g, dim3(256), 0, st, (const T*)feat, x, out, (const T*)wblob, mean, H, W, tx); }
+#define CALL(T, F_) SR_DISPATCH_R(CALLR, T, F_)
+  SR_DISPATCH_TF(CALL)
+#undef CALL
+#undef CALLR
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sr_tail_bwd_data(const float* dout, void* dfeat, const void* wblob, int N, int H, int W, int F,
+                                int R, int dtype, sr_stream_t stream) {
+  if (!dout || !dfeat || !wblob || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
+  hipStream_t st = (hipStream_t)stream;
+#define CALLR(T, F_, R_) { typedef EndsCfg<F_, R_> E; int tx; dim3 g = tile_grid<E>(N, H, W, &tx); \
+    hipLaunchKernelGGL((sr_tail_bwd_data_kernel<T, F_, R_>), g, dim3(256), 0, st, dout, (T*)dfeat, (const T*)wblob, H, W, tx); }
+#define CALL(T, F_) SR_DISPATCH_R(CALLR, T, F_)
+  SR_DISPATCH_TF(CALL)
+#undef CALL
+#undef CALLR
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sr_tail_wgrad(const float* dout, const void* feat, const float* x, float mean, float* partial,
+                             int wgs, int N, int H, int W, int F, int R, int dtype, sr_stream_t stream) {
+  if (!dout || !feat || !x || !partial || wgs <= 0 || N <= 0 || H <= 0 || W <= 0) return -2;
+  hipStream_t st = (hipStream_t)stream;
+#define CALLR(T, F_, R_) { typedef EndsCfg<F_, R_> E; const int tx = (W + E::TW - 1) / E::TW, tpi = tx * ((H + E::TH - 1) / E::TH); \
+    hipLaunchKernelGGL((sr_tail_wgrad_kernel<T, F_, R_>), dim3(wgs, 3), dim3(256), 0, st, dout, (const T*)feat, x, mean, partial, N, H, W, tx, tpi); }
+#define CALL(T, F_) SR_DISPATCH_R(CALLR, T, F_)
+  SR_DISPATCH_TF(CALL)
+#undef CALL
+#undef CALLR
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sr_head_wgrad(const void* dy0, const float* x, float mean, float* partial, int wgs, int N, int H,
+                             int W, int F, int dtype, sr_stream_t stream) {
+  if (!dy0 || !x || !partial || wgs <= 0 || N <= 0 || H <= 0 || W <= 0) return -2;
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(T, F_) { typedef EndsCfg<F_, 4> E; const int tx = (W + E::TW - 1) / E::TW, tpi = tx * ((H + E::TH - 1) / E::TH); \
+    hipLaunchKernelGGL((sr_head_wgrad_kernel<T, F_>), dim3(wgs), dim3(256), 0, st, (const T*)dy0, x, mean, partial, N, H, W, tx, tpi); }
+  SR_DISPATCH_TF(CALL)
+#undef CALL
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------

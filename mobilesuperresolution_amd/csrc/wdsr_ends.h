@@ -1,0 +1,448 @@
+// Head conv (3x3, 3->F) and fused tail (3x3, F->3r^2) + skip (5x5, 3->3r^2) + PixelShuffle(r) + mean,
+// forward and backward (gfx950).  Reference ops replaced: BASIC_MODEL.forward, models/basic_wdsr_b.py:85-93
+// (x - mean; head :32-42; tail :55-64; skip :66-78; shuf :80-83; + mean :92) and their autograd backward.
+//
+// The LR image is NCHW fp32 in HBM (the reference's layout) and is staged in LDS as [pixel][4]:
+// 3 colours minus the mean (zero outside the image = the conv's zero padding of x - mean) plus a ones
+// channel that carries the bias.  One 8-element fragment chunk = two horizontally adjacent pixels.
+// The HR output is written straight from the accumulator: with out^T tiles (rows = conv channel
+// c*r*r + i*r + j, lanes = LR pixel) the 4 registers of a group are the r = 4 sub-columns j of one HR row,
+// so PixelShuffle is pure addressing (no intermediate buffer, no cross-lane traffic).
+#pragma once
+#include "wdsr_block.h"
+
+template <int F_, int R_>
+struct EndsCfg {
+  static constexpr int F = F_, R = R_;
+  static constexpr int CO = 3 * R * R, NT = (CO + 31) / 32, COP = (CO + 7) / 8 * 8, CC = COP / 8, FC = F / 8;
+  static constexpr int KST = (9 * FC + 15 + 1) / 2, KSTB = (9 * CC + 1) / 2;
+  static constexpr int TH = 12, TW = 24, HW = TW + 2, HH = TH + 2, NPXH = HW * HH, NPXH_PAD = (NPXH + 31) / 32 * 32;
+  static constexpr int NPT_O = (TH / 4) * (TW / 8), NPXC = TH * TW;
+  static constexpr int FT_ELEMS = (NPXH_PAD + 2) * F;           // feature (or dy) tile with 1-px halo
+  static constexpr int DC_ELEMS = (NPXH_PAD + 2) * COP;         // dconv tile with 1-px halo
+  static constexpr int DCC_ELEMS = (NPXC + 2) * COP;            // dconv core tile
+  static constexpr int DYC_ELEMS = (NPXC + 2) * F;              // dy core tile (head wgrad)
+  template <int P> struct Img {                                 // LR image tile with P-px halo
+    static constexpr int IW = TW + 2 * P, IH = TH + 2 * P, NPI = IW * IH, ELEMS = (NPI + 8) * 4;
+  };
+  static constexpr int TAIL_TILES = 14 * NT;                    // 9 taps + 5 skip rows, NT row tiles each
+};
+
+// 8 elements from an LDS image at an offset that is only 4-element aligned
+template <typename T> SR_DEV typename FragOf<T>::type lds_chunk_half(const T* img, int off) {
+  typedef typename FragOf<T>::half_type HalfT;
+  const HalfT lo = *reinterpret_cast<const HalfT*>(img + off);
+  const HalfT hi = *reinterpret_cast<const HalfT*>(img + off + 4);
+  typename FragOf<T>::type f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+
+template <typename T, typename E, int P>
+SR_DEV void stage_img(T* XI, const float* __restrict__ ximg, float mean, int H, int W, int ty0, int tx0, int tid) {
+  typedef typename FragOf<T>::half_type HalfT;
+  typedef typename E::template Img<P> I;
+  const size_t plane = (size_t)H * W;
+  for (int ip = tid; ip < I::NPI + 8; ip += 256) {
+    HalfT v;
+    v[0] = (T)0.f; v[1] = (T)0.f; v[2] = (T)0.f; v[3] = (T)1.f;
+    if (ip < I::NPI) {
+      const int iy = ip / I::IW, ix = ip - iy * I::IW;
+      const int Y = ty0 - P + iy, X = tx0 - P + ix;
+      if (Y >= 0 && Y < H && X >= 0 && X < W) {
+        const size_t o = (size_t)Y * W + X;
+        v[0] = (T)(ximg[o] - mean);
+        v[1] = (T)(ximg[plane + o] - mean);
+        v[2] = (T)(ximg[2 * plane + o] - mean);
+      }
+    }
+    *reinterpret_cast<HalfT*>(XI + ip * 4) = v;
+  }
+}
+
+// feature / gradient tile with a 1-pixel halo: [NPXH_PAD + 2][CH] (CH multiple of 8), zero outside
+template <typename T, typename E, int CH>
+SR_DEV void stage_halo(T* dst, const T* __restrict__ src, int H, int W, int ty0, int tx0, int tid) {
+  typedef typename FragOf<T>::type FragT;
+  constexpr int NC = CH / 8;
+  for (int idx = tid; idx < (E::NPXH_PAD + 2) * NC; idx += 256) {
+    const int hp = idx / NC, c = idx - hp * NC;
+    FragT v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (T)0.f;
+    if (hp < E::NPXH) {
+      const int hy = hp / E::HW, hx = hp - hy * E::HW;
+      const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
+      if (Y >= 0 && Y < H && X >= 0 && X < W) v = *reinterpret_cast<const FragT*>(src + ((size_t)Y * W + X) * CH + c * 8);
+    }
+    *reinterpret_cast<FragT*>(dst + hp * CH + c * 8) = v;
+  }
+}
+
+template <typename T, typename E, int CH>
+SR_DEV void stage_core(T* dst, const T* __restrict__ src, int H, int W, int ty0, int tx0, int tid) {
+  typedef typename FragOf<T>::type FragT;
+  constexpr int NC = CH / 8;
+  for (int idx = tid; idx < (E::NPXC + 2) * NC; idx += 256) {
+    const int pc = idx / NC, c = idx - pc * NC;
+    FragT v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (T)0.f;
+    if (pc < E::NPXC) {
+      const int Y = ty0 + pc / E::TW, X = tx0 + pc % E::TW;
+      if (Y < H && X < W) v = *reinterpret_cast<const FragT*>(src + ((size_t)Y * W + X) * CH + c * 8);
+    }
+    *reinterpret_cast<FragT*>(dst + pc * CH + c * 8) = v;
+  }
+}
+
+// un-shuffle the HR gradient (NCHW fp32, N x 3 x RH x RW) into a dconv tile [px][COP]:
+// channel c*R*R + i*R + j of LR pixel (Y, X) = dout[c][Y*R + i][X*R + j].  HALO = 1: tile with halo,
+// HALO = 0: core tile.
+template <typename T, typename E, int HALO>
+SR_DEV void stage_dconv(T* DC, const float* __restrict__ dout, int H, int W, int ty0, int tx0, int tid) {
+  constexpr int R = E::R;
+  constexpr int NPX = HALO ? (E::NPXH_PAD + 2) : (E::NPXC + 2);
+  constexpr int NLIVE = HALO ? E::NPXH : E::NPXC;
+  constexpr int TWW = HALO ? E::HW : E::TW;
+  const size_t hrw = (size_t)W * R, plane = (size_t)H * R * hrw;
+  constexpr int ROWS = 3 * R;                       // (colour, sub-row) pairs per pixel
+  for (int idx = tid; idx < NPX * ROWS; idx += 256) {
+    const int p = idx / ROWS, cr = idx - p * ROWS;
+    const int c = cr / R, si = cr - c * R;
+    float v[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) v[j] = 0.f;
+    if (p < NLIVE) {
+      const int py = p / TWW, px = p - py * TWW;
+      const int Y = ty0 - HALO + py, X = tx0 - HALO + px;
+      if (Y >= 0 && Y < H && X >= 0 && X < W) {
+        const float* s = dout + c * plane + ((size_t)Y * R + si) * hrw + (size_t)X * R;
+        if constexpr (R == 4) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(s);
+          v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+        } else {
+#pragma unroll
+          for (int j = 0; j < R; ++j) v[j] = s[j];
+        }
+      }
+    }
+    T* d = DC + p * E::COP + c * R * R + si * R;
+    if constexpr (R == 4) {
+      typename FragOf<T>::half_type hv;
+      hv[0] = (T)v[0]; hv[1] = (T)v[1]; hv[2] = (T)v[2]; hv[3] = (T)v[3];
+      *reinterpret_cast<typename FragOf<T>::half_type*>(d) = hv;
+    } else {
+#pragma unroll
+      for (int j = 0; j < R; ++j) d[j] = (T)v[j];
+    }
+  }
+  if constexpr (E::COP > E::CO) {                    // zero the padding channels
+    for (int idx = tid; idx < NPX * (E::COP - E::CO); idx += 256) {
+      const int p = idx / (E::COP - E::CO), k = idx - p * (E::COP - E::CO);
+      DC[p * E::COP + E::CO + k] = (T)0.f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// head forward: y[n, Y, X, :] = conv3x3(x - mean) + b   (NCHW fp32 image -> NHWC T features)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int F>
+__global__ __launch_bounds__(256) void sr_head_fwd_kernel(const float* __restrict__ ximg, T* __restrict__ y,
+                                                          const T* __restrict__ wblob, float mean, int H, int W,
+                                                          int tiles_x) {
+  typedef EndsCfg<F, 4> E;
+  typedef typename E::template Img<1> I;
+  typedef typename FragOf<T>::half_type HalfT;
+  __shared__ __attribute__((aligned(16))) T XI[I::ELEMS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const int ty0 = (tile / tiles_x) * E::TH, tx0 = (tile % tiles_x) * E::TW;
+  stage_img<T, E, 1>(XI, ximg + (size_t)n * 3 * H * W, mean, H, W, ty0, tx0, tid);
+  __syncthreads();
+  for (int ot = wave; ot < E::NPT_O; ot += 4) {
+    const int oy = (ot / (E::TW / 8)) * 4 + (r >> 3), ox = (ot % (E::TW / 8)) * 8 + (r & 7);
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int q = 2 * s + hh, ky = q >> 1, m = q & 1;
+      acc = mma16<T>(load_wfrag<T>(wblob, s, lane), lds_chunk_half<T>(XI, ((oy + ky) * I::IW + ox + 2 * m) * 4), acc);
+    }
+    const int Y = ty0 + oy, X = tx0 + ox;
+    if (Y < H && X < W) {
+      T* yo = y + (((size_t)n * H + Y) * W + X) * F;
+#pragma unroll
+      for (int g = 0; g < E::FC; ++g) *reinterpret_cast<HalfT*>(yo + g * 8 + hh * 4) = acc_group<T>(acc, g);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tail forward: out = PixelShuffle_R( conv3x3(feat; Wt) + conv5x5(x - mean; Ws) + bt + bs ) + mean
+// (the three constants ride on the image's ones channel at the skip's centre tap)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int F, int R>
+__global__ __launch_bounds__(256) void sr_tail_fwd_kernel(const T* __restrict__ feat, const float* __restrict__ ximg,
+                                                          float* __restrict__ out, const T* __restrict__ wblob,
+                                                          float mean, int H, int W, int tiles_x) {
+  typedef EndsCfg<F, R> E;
+  typedef typename E::template Img<2> I;
+  typedef typename FragOf<T>::type FragT;
+  __shared__ __attribute__((aligned(16))) T smem[E::FT_ELEMS + I::ELEMS];
+  T* const FT = smem;
+  constexpr int XI0 = E::FT_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const int ty0 = (tile / tiles_x) * E::TH, tx0 = (tile % tiles_x) * E::TW;
+  stage_halo<T, E, F>(FT, feat + (size_t)n * H * W * F, H, W, ty0, tx0, tid);
+  stage_img<T, E, 2>(smem + XI0, ximg + (size_t)n * 3 * H * W, mean, H, W, ty0, tx0, tid);
+  __syncthreads();
+  constexpr bool HOIST = (sizeof(T) == 2) && (E::NT * E::KST <= 42);
+  const T* const wblob0 = wblob;
+  for (int ot = wave; ot < E::NPT_O; ot += 4) {
+    wblob = weights_for_tile<HOIST>(wblob0);
+    const int oy = (ot / (E::TW / 8)) * 4 + (r >> 3), ox = (ot % (E::TW / 8)) * 8 + (r & 7);
+    const int hbase = oy * E::HW + ox;
+    f32x16 acc[E::NT];
+#pragma unroll
+    for (int ti = 0; ti < E::NT; ++ti) acc[ti] = zero16();
+#pragma unroll
+    for (int s = 0; s < E::KST; ++s) {
+      const int q = 2 * s + hh;
+      FragT b;
+      if (2 * s + 1 < 9 * E::FC) {                          // both lane halves read feature chunks
+        const int tap = q / E::FC, c = q - tap * E::FC;
+        b = lds_chunk<T>(smem, (hbase + (tap / 3) * E::HW + (tap % 3)) * F + c * 8);
+      } else {
+        int off;
+        if (q < 9 * E::FC) {
+          const int tap = q / E::FC, c = q - tap * E::FC;
+          off = (hbase + (tap / 3) * E::HW + (tap % 3)) * F + c * 8;
+        } else {
+          int qs = q - 9 * E::FC;
+          if (qs >= 15) qs = 0;                             // zero weights there
+          const int ky = qs / 3, m = qs - ky * 3;
+          off = XI0 + ((oy + ky) * I::IW + ox + 2 * m) * 4;
+        }
+        b = lds_chunk_half<T>(smem, off);
+      }
+#pragma unroll
+      for (int ti = 0; ti < E::NT; ++ti) acc[ti] = mma16<T>(load_wfrag<T>(wblob, ti * E::KST + s, lane), b, acc[ti]);
+    }
+    const int Y = ty0 + oy, X = tx0 + ox;
+    if (Y < H && X < W) {
+      const size_t hrw = (size_t)W * R, plane = (size_t)H * R * hrw;
+      float* o = out + (size_t)n * 3 * plane;
+#pragma unroll
+      for (int ti = 0; ti < E::NT; ++ti) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ch0 = 32 * ti + 8 * g + 4 * hh;         // rows ch0 .. ch0+3 live in regs 4g..4g+3
+          if constexpr (R == 4) {
+            if (ch0 < E::CO) {
+              const int c = ch0 >> 4, si = (ch0 >> 2) & 3;
+              f32x4 v;
+              v[0] = acc[ti][4 * g]; v[1] = acc[ti][4 * g + 1]; v[2] = acc[ti][4 * g + 2]; v[3] = acc[ti][4 * g + 3];
+              *reinterpret_cast<f32x4*>(o + c * plane + ((size_t)Y * 4 + si) * hrw + (size_t)X * 4) = v;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int ch = ch0 + j;
+              if (ch < E::CO) {
+                const int c = ch / (R * R), rem = ch - c * R * R, si = rem / R, sj = rem - si * R;
+                o[c * plane + ((size_t)Y * R + si) * hrw + (size_t)X * R + sj] = acc[ti][4 * g + j];
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tail backward-data: dfeat[px, f] = sum_{u, ch} Wt[ch, f, 8-u] dconv[px + u - 1, ch]
+// ---------------------------------------------------------------------------------------------
+template <typename T, int F, int R>
+__global__ __launch_bounds__(256) void sr_tail_bwd_data_kernel(const float* __restrict__ dout, T* __restrict__ dfeat,
+                                                               const T* __restrict__ wblob, int H, int W,
+                                                               int tiles_x) {
+  typedef EndsCfg<F, R> E;
+  typedef typename FragOf<T>::half_type HalfT;
+  __shared__ __attribute__((aligned(16))) T DC[E::DC_ELEMS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const int ty0 = (tile / tiles_x) * E::TH, tx0 = (tile % tiles_x) * E::TW;
+  stage_dconv<T, E, 1>(DC, dout + (size_t)n * 3 * H * R * W * R, H, W, ty0, tx0, tid);
+  __syncthreads();
+  const T* wt = wblob + (size_t)E::NT * E::KST * 512;        // backward-data section follows the forward one
+  constexpr bool HOIST = (sizeof(T) == 2);
+  const T* const wt0 = wt;
+  for (int ot = wave; ot < E::NPT_O; ot += 4) {
+    wt = weights_for_tile<HOIST>(wt0);
+    const int oy = (ot / (E::TW / 8)) * 4 + (r >> 3), ox = (ot % (E::TW / 8)) * 8 + (r & 7);
+    const int hbase = oy * E::HW + ox;
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int s = 0; s < E::KSTB; ++s) {
+      const int q = 2 * s + hh;
+      int off = hbase * E::COP;
+      if (q < 9 * E::CC) {
+        const int u = q / E::CC, c = q - u * E::CC;
+        off = (hbase + (u / 3) * E::HW + (u % 3)) * E::COP + c * 8;
+      }
+      acc = mma16<T>(load_wfrag<T>(wt, s, lane), lds_chunk<T>(DC, off), acc);
+    }
+    const int Y = ty0 + oy, X = tx0 + ox;
+    if (Y < H && X < W) {
+      T* o = dfeat + (((size_t)n * H + Y) * W + X) * F;
+#pragma unroll
+      for (int g = 0; g < E::FC; ++g) *reinterpret_cast<HalfT*>(o + g * 8 + hh * 4) = acc_group<T>(acc, g);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tail weight gradients.  blockIdx.y = role (0..2): role k owns the three taps of tail row ky = k and the
+// skip rows {0,1}, {2,3}, {4}; every accumulator tile is [conv channel rows, input columns], pixels
+// contracted through transposed LDS reads.  Slab: [TAIL_TILES][16][64] per workgroup (roles write
+// disjoint tiles); layout in packing.ends_grad_tables.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int F, int R>
+__global__ __launch_bounds__(256, 1) void sr_tail_wgrad_kernel(const float* __restrict__ dout, const T* __restrict__ feat,
+                                                               const float* __restrict__ ximg, float mean,
+                                                               float* __restrict__ partial, int N, int H, int W,
+                                                               int tiles_x, int tiles_per_img) {
+  typedef EndsCfg<F, R> E;
+  typedef typename E::template Img<2> I;
+  typedef typename FragOf<T>::type FragT;
+  constexpr int NT = E::NT;
+  constexpr int MAXT = 5 * NT;                               // 3 taps + up to 2 skip rows
+  constexpr int STAGE_BYTES = (E::DCC_ELEMS + E::FT_ELEMS + I::ELEMS) * (int)sizeof(T);
+  constexpr int SLAB_BYTES = MAXT * 1024 * 4;
+  constexpr int LDS_BYTES = STAGE_BYTES > SLAB_BYTES ? STAGE_BYTES : SLAB_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES];
+  T* const DC = reinterpret_cast<T*>(smem_raw);
+  T* const FT = DC + E::DCC_ELEMS;
+  T* const XI = FT + E::FT_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int role = blockIdx.y;
+  const int sk0 = 2 * role, nsk = (role == 2) ? 1 : 2;       // skip rows sk0 .. sk0 + nsk - 1
+
+  f32x16 acc[MAXT];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) acc[i] = zero16();
+
+  for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
+    const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
+    const int ty0 = (tile / tiles_x) * E::TH, tx0 = (tile % tiles_x) * E::TW;
+    __syncthreads();
+    stage_dconv<T, E, 0>(DC, dout + (size_t)n * 3 * H * R * W * R, H, W, ty0, tx0, tid);
+    stage_halo<T, E, F>(FT, feat + (size_t)n * H * W * F, H, W, ty0, tx0, tid);
+    stage_img<T, E, 2>(XI, ximg + (size_t)n * 3 * H * W, mean, H, W, ty0, tx0, tid);
+    __syncthreads();
+    for (int ot = wave; ot < E::NPT_O; ot += 4) {
+      const int toy = (ot / (E::TW / 8)) * 4, tox = (ot % (E::TW / 8)) * 8;
+      FragT dcT[NT][2];
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          dcT[ti][s] = tr_frag<T>(DC, s, lane, [=](int p) { return ((toy + (p >> 3)) * E::TW + tox + (p & 7)) * E::COP + 32 * ti; });
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const FragT b = tr_frag<T>(FT, s, lane, [=](int p) {
+            return ((toy + (p >> 3) + role) * E::HW + tox + (p & 7) + kx) * F;
+          });
+#pragma unroll
+          for (int ti = 0; ti < NT; ++ti) acc[kx * NT + ti] = mma16<T>(dcT[ti][s], b, acc[kx * NT + ti]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (k < nsk) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const FragT b = tr_frag<T>(XI, s, lane, [=](int p) {
+              return ((toy + (p >> 3) + sk0 + k) * I::IW + tox + (p & 7)) * 4;
+            });
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) acc[(3 + k) * NT + ti] = mma16<T>(dcT[ti][s], b, acc[(3 + k) * NT + ti]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* slab = reinterpret_cast<float*>(smem_raw);
+  for (int i = tid; i < MAXT * 1024; i += 256) slab[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) slab_add_tile(slab, i, acc[i], lane);
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.x * E::TAIL_TILES * 1024;
+  // local tile i -> global tile: taps (role*3 + kx)*NT + ti ; skip rows 9*NT + (sk0 + k)*NT + ti
+  const int nloc = (3 + nsk) * NT;
+  for (int i = tid; i < nloc * 1024; i += 256) {
+    const int lt = i >> 10, w = i & 1023;
+    const int grp = lt / NT, ti = lt - grp * NT;
+    const int gt = (grp < 3) ? ((role * 3 + grp) * NT + ti) : (9 * NT + (sk0 + grp - 3) * NT + ti);
+    out[gt * 1024 + w] = slab[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// head weight gradient: tiles [ky] = [f rows, (kx, ci) columns], dy0 = gradient w.r.t. the head output
+// ---------------------------------------------------------------------------------------------
+template <typename T, int F>
+__global__ __launch_bounds__(256, 1) void sr_head_wgrad_kernel(const T* __restrict__ dy0, const float* __restrict__ ximg,
+                                                               float mean, float* __restrict__ partial, int N, int H,
+                                                               int W, int tiles_x, int tiles_per_img) {
+  typedef EndsCfg<F, 4> E;
+  typedef typename E::template Img<1> I;
+  typedef typename FragOf<T>::type FragT;
+  constexpr int STAGE_BYTES = (E::DYC_ELEMS + I::ELEMS) * (int)sizeof(T);
+  constexpr int SLAB_BYTES = 3 * 1024 * 4;
+  constexpr int LDS_BYTES = STAGE_BYTES > SLAB_BYTES ? STAGE_BYTES : SLAB_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES];
+  T* const DY = reinterpret_cast<T*>(smem_raw);
+  T* const XI = DY + E::DYC_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  f32x16 acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) acc[i] = zero16();
+  for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
+    const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
+    const int ty0 = (tile / tiles_x) * E::TH, tx0 = (tile % tiles_x) * E::TW;
+    __syncthreads();
+    stage_core<T, E, F>(DY, dy0 + (size_t)n * H * W * F, H, W, ty0, tx0, tid);
+    stage_img<T, E, 1>(XI, ximg + (size_t)n * 3 * H * W, mean, H, W, ty0, tx0, tid);
+    __syncthreads();
+    for (int ot = wave; ot < E::NPT_O; ot += 4) {
+      const int toy = (ot / (E::TW / 8)) * 4, tox = (ot % (E::TW / 8)) * 8;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const FragT a = tr_frag<T>(DY, s, lane, [=](int p) { return ((toy + (p >> 3)) * E::TW + tox + (p & 7)) * F; });
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const FragT b = tr_frag<T>(XI, s, lane, [=](int p) { return ((toy + (p >> 3) + ky) * I::IW + tox + (p & 7)) * 4; });
+          acc[ky] = mma16<T>(a, b, acc[ky]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* slab = reinterpret_cast<float*>(smem_raw);
+  for (int i = tid; i < 3 * 1024; i += 256) slab[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 3; ++i) slab_add_tile(slab, i, acc[i], lane);
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.x * 3 * 1024;
+  for (int i = tid; i < 3 * 1024; i += 256) out[i] = slab[i];
+}

@@ -95,3 +95,80 @@ def block_wgrad(xs: torch.Tensor, dys: torch.Tensor, blob: torch.Tensor, cinit: 
     slab = torch.cat([pa.sum(1), pb.sum(1)], dim=1)
     g = slab.index_select(1, tb["grad"])
     return torch.cat([g, g.new_zeros(nb, 2)], dim=1)
+
+
+# =====================================================================================
+# head / tail (+ skip + PixelShuffle)
+# =====================================================================================
+@lru_cache(maxsize=None)
+def _dev_ends_tables(F: int, R: int, device_index: int):
+    tab = P.ends_tables(F, R)
+    gt = P.ends_grad_tables(F, R)
+    dev = torch.device("cuda", device_index)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    g = tab["geom"]
+    return dict(head=t(tab["head"]), tail=t(tab["tail"]), head_grad=t(gt["head"]), tail_grad=t(gt["tail"]),
+                tail_slab=gt["tail_size"], head_slab=gt["head_size"], geom=g,
+                head_size=g.head_off["size"], tail_size=g.tail_off["size"])
+
+
+def ends_tables(F: int, R: int, device: torch.device):
+    return _dev_ends_tables(F, R, device.index if device.index is not None else torch.cuda.current_device())
+
+
+def head_src(wh: torch.Tensor, bh: torch.Tensor) -> torch.Tensor:
+    """canonical head source: wh (F,3,3,3) | bh (F) | 0 | 1"""
+    return torch.cat([wh.reshape(-1), bh, wh.new_tensor([0.0, 1.0])])
+
+
+def tail_src(wt: torch.Tensor, ws: torch.Tensor, btot: torch.Tensor) -> torch.Tensor:
+    """canonical tail source: wt (CO,F,3,3) | ws (CO,3,5,5) | bt + bs + mean (CO) | 0 | 1"""
+    return torch.cat([wt.reshape(-1), ws.reshape(-1), btot, wt.new_tensor([0.0, 1.0])])
+
+
+def pack_ends(src_head: torch.Tensor, src_tail: torch.Tensor, F: int, R: int, dtype: torch.dtype):
+    tb = ends_tables(F, R, src_head.device)
+    assert src_head.numel() == tb["head_size"] and src_tail.numel() == tb["tail_size"]
+    bh = src_head.detach().float().index_select(0, tb["head"]).to(dtype).contiguous()
+    bt = src_tail.detach().float().index_select(0, tb["tail"]).to(dtype).contiguous()
+    return bh, bt
+
+
+def head_fwd(x: torch.Tensor, y: torch.Tensor, blob: torch.Tensor, mean: float):
+    n, _, h, w = x.shape
+    L.check(L.lib().sr_head_fwd(L.ptr(x), L.ptr(y), L.ptr(blob), mean, n, h, w, y.shape[-1],
+                                L.DTYPE_CODE[y.dtype], L.stream_ptr()), "sr_head_fwd")
+
+
+def tail_fwd(feat: torch.Tensor, x: torch.Tensor, out: torch.Tensor, blob: torch.Tensor, mean: float, R: int):
+    n, h, w, f = feat.shape
+    L.check(L.lib().sr_tail_fwd(L.ptr(feat), L.ptr(x), L.ptr(out), L.ptr(blob), mean, n, h, w, f, R,
+                                L.DTYPE_CODE[feat.dtype], L.stream_ptr()), "sr_tail_fwd")
+
+
+def tail_bwd_data(dout: torch.Tensor, dfeat: torch.Tensor, blob: torch.Tensor, R: int):
+    n, h, w, f = dfeat.shape
+    L.check(L.lib().sr_tail_bwd_data(L.ptr(dout), L.ptr(dfeat), L.ptr(blob), n, h, w, f, R,
+                                     L.DTYPE_CODE[dfeat.dtype], L.stream_ptr()), "sr_tail_bwd_data")
+
+
+def tail_wgrad(dout: torch.Tensor, feat: torch.Tensor, x: torch.Tensor, mean: float, R: int,
+               wgs: int = 64) -> torch.Tensor:
+    """returns d_src_tail (zeros at the constant slots)"""
+    n, h, w, f = feat.shape
+    tb = ends_tables(f, R, feat.device)
+    part = torch.empty((wgs, tb["tail_slab"]), dtype=torch.float32, device=feat.device)
+    L.check(L.lib().sr_tail_wgrad(L.ptr(dout), L.ptr(feat), L.ptr(x), mean, L.ptr(part), wgs, n, h, w, f, R,
+                                  L.DTYPE_CODE[feat.dtype], L.stream_ptr()), "sr_tail_wgrad")
+    g = part.sum(0).index_select(0, tb["tail_grad"])
+    return torch.cat([g, g.new_zeros(2)])
+
+
+def head_wgrad(dy0: torch.Tensor, x: torch.Tensor, mean: float, wgs: int = 64) -> torch.Tensor:
+    n, h, w, f = dy0.shape
+    tb = ends_tables(f, 4, dy0.device)
+    part = torch.empty((wgs, tb["head_slab"]), dtype=torch.float32, device=dy0.device)
+    L.check(L.lib().sr_head_wgrad(L.ptr(dy0), L.ptr(x), mean, L.ptr(part), wgs, n, h, w, f,
+                                  L.DTYPE_CODE[dy0.dtype], L.stream_ptr()), "sr_head_wgrad")
+    g = part.sum(0).index_select(0, tb["head_grad"])
+    return torch.cat([g, g.new_zeros(2)])

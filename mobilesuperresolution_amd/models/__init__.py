@@ -1,0 +1,33 @@
+"""Host-side mirror of the reference's `models` package for the SR hot path
+(reference: models/__init__.py:5-6,31-32).  `get_model(params)` resolves
+`params.model_type` exactly as the reference's `eval(params.model_type)(params)` does."""
+from __future__ import annotations
+
+import argparse
+
+from .basic_wdsr_b import BASIC_MODEL
+
+__all__ = ["BASIC_MODEL", "get_model", "update_argparser"]
+
+_REGISTRY = {"BASIC_MODEL": BASIC_MODEL}
+
+
+def update_argparser(parser: argparse.ArgumentParser):
+    """The model flags the trainers pass through (reference: models/__init__.py:9-29)."""
+    parser.add_argument('--learning_rate', help='Learning rate.', default=0.001, type=float)
+    parser.add_argument('--pretrained', action='store_true', default=False)
+    parser.add_argument('--width_search', action='store_true', default=False, help='Width Search.')
+    parser.add_argument('--length_search', action='store_true', default=False)
+    parser.add_argument('--num_blocks', help='Number of residual blocks in networks.', default=16, type=int)
+    parser.add_argument('--num_residual_units', help='Number of residual units in networks.', default=24, type=int)
+    parser.add_argument('--hot_dtype', help='MI355X hot-path storage/compute type: fp32 (exact) or bf16.',
+                        default=None, type=str)
+
+
+def get_model(params):
+    try:
+        cls = _REGISTRY[params.model_type]
+    except KeyError:
+        raise NotImplementedError(
+            f"model_type {params.model_type!r} is not on the MI355X hot path (have {sorted(_REGISTRY)})")
+    return cls(params)
