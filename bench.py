@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the MI355X SR hot path: HR megapixels/s of a WDSR-B x4 training step.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic 48x48 LR patches already resident
+in HBM: forward (head, 16 fused residual blocks, fused tail+skip+PixelShuffle), L1 loss, backward,
+Adam step -- what pretrain.py's train() does per batch (reference pretrain.py:61-80).  Workload at
+every N: BASELINE.json configs[1] (x4, 16 blocks / 24 units, bf16 storage, batch 32 per GPU, weak
+scaling); for N > 1 the model is wrapped in DistributedDataParallel over RCCL as pretrain.py:239 does.
+
+Rank 0 prints ONE JSON line (metric, value, ..., roofline, cpu_baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HR_MPIX_PER_PATCH = (48 * 4) ** 2 / 1e6          # 0.036864
+HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BATCH, LR, SCALE, BLOCKS, UNITS = 32, 48, 4, 16, 24
+
+
+def model_ns(dtype="bf16"):
+    return argparse.Namespace(model_type="BASIC_MODEL", image_mean=0.5, num_channels=3, scale=SCALE,
+                              num_blocks=BLOCKS, num_residual_units=UNITS, hot_dtype=dtype)
+
+
+def algorithmic_bytes(n, h, w, f, nb, r, s):
+    """Algorithmic HBM bytes per launch: minimal tensor reads + writes, weights excluded."""
+    px = n * h * w
+    return {
+        "sr_wdsr_block_fwd": 2 * px * f * s,                         # read x, write y
+        "sr_wdsr_block_bwd_data": 3 * px * f * s,                    # read x, dy; write dx
+        "sr_wdsr_block_wgrad": nb * 2 * px * f * s,                  # read x, dy of every block (one call)
+        "sr_head_fwd": px * (3 * 4 + f * s),
+        "sr_tail_fwd": px * (f * s + 3 * 4 + 3 * r * r * 4),
+        "sr_tail_bwd_data": px * (3 * r * r * 4 + f * s),
+        "sr_tail_wgrad": px * (3 * r * r * 4 + f * s + 3 * 4),
+        "sr_head_wgrad": px * (f * s + 3 * 4),
+    }
+
+
+def cpu_baseline(budget_s=20.0):
+    """The oracle (plain PyTorch fp32 restatement of the reference, parity-pinned) timed on this box's
+    host cores on the same workload shape: full train step, batch 32, 16 blocks / 24 units."""
+    from oracle.wdsr_oracle import OracleBasicModel
+    torch.manual_seed(0)
+    m = OracleBasicModel(model_ns()).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    x = torch.rand(BATCH, 3, LR, LR)
+    hr = torch.rand(BATCH, 3, LR * SCALE, LR * SCALE)
+
+    def step():
+        opt.zero_grad()
+        loss = torch.nn.functional.l1_loss(m(x), hr)
+        loss.backward()
+        opt.step()
+
+    step()
+    t0, n = time.perf_counter(), 0
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 20:
+            break
+    return {"value": round(BATCH * HR_MPIX_PER_PATCH * n / el, 4), "unit": "HR-Mpix/s",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full train steps (fwd+L1+bwd+Adam) of the same workload, batch {BATCH}, fp32, "
+                      f"{el:.1f} s on {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://")        # nccl == RCCL on ROCm
+
+    from mobilesuperresolution_amd import hotpath as HP
+    from mobilesuperresolution_amd.models import get_model
+
+    torch.manual_seed(0)                                # identical replicas (DDP broadcasts rank 0 anyway)
+    model = get_model(model_ns(args.dtype)).to(dev).train()
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
+                                                        gradient_as_bucket_view=True, broadcast_buffers=False)
+    lr_rate = 1e-3 * world                              # pretrain.py:216 linear scaling
+    try:
+        opt = torch.optim.Adam(model.parameters(), lr=lr_rate, fused=True)
+    except Exception:
+        opt = torch.optim.Adam(model.parameters(), lr=lr_rate, foreach=True)
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)   # each rank its own shard of synthetic patches
+    x = torch.rand(BATCH, 3, LR, LR, generator=g).to(dev)
+    hr = torch.rand(BATCH, 3, LR * SCALE, LR * SCALE, generator=g).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        sr = net(x)
+        loss = torch.nn.functional.l1_loss(sr, hr)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = float(loss)
+
+    # forward-only (inference) throughput, same batch
+    model.eval()
+    with torch.no_grad():
+        for _ in range(3):
+            model(x)
+        torch.cuda.synchronize()
+        tf = time.perf_counter()
+        for _ in range(args.steps):
+            model(x)
+        torch.cuda.synchronize()
+        fwd_elapsed = time.perf_counter() - tf
+    model.train()
+
+    if rank == 0:
+        # ---- roofline leg: the same steps, every kernel launch bracketed by HIP events on its stream ----
+        timer = HP.KernelTimer()
+        HP.set_timer(timer)
+        for _ in range(max(3, min(args.steps, 10))):
+            step()
+        HP.set_timer(None)
+        summ = timer.summary()
+        s = 2 if args.dtype == "bf16" else 4
+        alg = algorithmic_bytes(BATCH, LR, LR, UNITS, BLOCKS, SCALE, s)
+        steps_timed = max(3, min(args.steps, 10))
+        kernels = {}
+        for name, (cnt, ms) in summ.items():
+            kernels[name] = {"launches_per_step": cnt // steps_timed, "avg_us": round(ms * 1e3, 2),
+                             "alg_GBps": round(alg[name] / (ms * 1e-3) / 1e9, 1)}
+        dom = "sr_wdsr_block_fwd"                        # the graded unit
+        ms = summ[dom][1]
+        achieved = alg[dom] / (ms * 1e-3) / 1e9
+        by_time = max(summ, key=lambda k: summ[k][0] * summ[k][1])
+        roofline = {"kernel": "wdsr_block_fwd_kernel<bf16,24,144,20>" if args.dtype == "bf16" else "wdsr_block_fwd_kernel<float,24,144,20>",
+                    "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "alg_bytes_per_launch": alg[dom], "avg_launch_us": round(ms * 1e3, 2),
+                    "largest_time_share": by_time}
+        out = {
+            "metric": "HR megapixels/sec (WDSR-B x4, 48x48 LR patches), full training step",
+            "value": round(world * BATCH * HR_MPIX_PER_PATCH * args.steps / elapsed, 2),
+            "unit": "HR-Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"WDSR-B x{SCALE}, {BLOCKS} blocks / {UNITS} units, {LR}x{LR} LR patches, "
+                                   f"batch {BATCH} per GPU, fwd+L1+bwd+Adam" + (", DDP/RCCL" if world > 1 else ""),
+                       "global_batch": BATCH * world, "parallelism": f"dp{world}"},
+            "forward_only_HR_Mpix_s": round(BATCH * HR_MPIX_PER_PATCH * args.steps / fwd_elapsed, 2),
+            "final_loss": round(final_loss, 5),
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

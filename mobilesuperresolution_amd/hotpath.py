@@ -14,6 +14,39 @@ from . import _lib as L
 from . import packing as P
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).
+    Off by default: the product path records nothing."""
+
+    def __init__(self):
+        self.events = {}
+
+    def run(self, name, fn, *args):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        self.events.setdefault(name, []).append((e0, e1))
+        return rc
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.events.items()}
+
+
+_TIMER = None
+
+
+def set_timer(t):
+    global _TIMER
+    _TIMER = t
+
+
+def _launch(name, fn, *args):
+    rc = fn(*args) if _TIMER is None else _TIMER.run(name, fn, *args)
+    L.check(rc, name)
+
+
 def block_dims(F: int) -> Tuple[int, int, int]:
     """(F, E, L) of the reference Block: expand 6, linear 0.84 (models/basic_wdsr_b.py:105-106)."""
     return F, int(F * 6), int(F * 0.84)
@@ -67,16 +100,15 @@ def pack_blocks(src_all: torch.Tensor, F: int, dtype: torch.dtype):
 
 def block_fwd(x: torch.Tensor, y: torch.Tensor, blob_i: torch.Tensor, cinit_i: torch.Tensor):
     n, h, w, f = x.shape
-    L.check(L.lib().sr_wdsr_block_fwd(L.ptr(x), L.ptr(y), L.ptr(blob_i), L.ptr(cinit_i), n, h, w, f,
-                                      L.DTYPE_CODE[x.dtype], L.stream_ptr()), "sr_wdsr_block_fwd")
+    _launch("sr_wdsr_block_fwd", L.lib().sr_wdsr_block_fwd, L.ptr(x), L.ptr(y), L.ptr(blob_i), L.ptr(cinit_i), n, h, w, f,
+                                      L.DTYPE_CODE[x.dtype], L.stream_ptr())
 
 
 def block_bwd_data(x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, blob_i: torch.Tensor,
                    cinit_i: torch.Tensor):
     n, h, w, f = x.shape
-    L.check(L.lib().sr_wdsr_block_bwd_data(L.ptr(x), L.ptr(dy), L.ptr(dx), L.ptr(blob_i), L.ptr(cinit_i),
-                                           n, h, w, f, L.DTYPE_CODE[x.dtype], L.stream_ptr()),
-            "sr_wdsr_block_bwd_data")
+    _launch("sr_wdsr_block_bwd_data", L.lib().sr_wdsr_block_bwd_data, L.ptr(x), L.ptr(dy), L.ptr(dx), L.ptr(blob_i), L.ptr(cinit_i),
+                                           n, h, w, f, L.DTYPE_CODE[x.dtype], L.stream_ptr())
 
 
 def block_wgrad(xs: torch.Tensor, dys: torch.Tensor, blob: torch.Tensor, cinit: torch.Tensor,
@@ -88,10 +120,10 @@ def block_wgrad(xs: torch.Tensor, dys: torch.Tensor, blob: torch.Tensor, cinit: 
     pa = torch.empty((nb, wgs_per_layer, tb["slab_a"]), dtype=torch.float32, device=xs.device)
     pb = torch.empty((nb, wgs_per_layer, tb["slab_b"]), dtype=torch.float32, device=xs.device)
     assert xs.is_contiguous() and dys.is_contiguous() and blob.is_contiguous() and cinit.is_contiguous()
-    L.check(L.lib().sr_wdsr_block_wgrad(L.ptr(xs), L.ptr(dys), L.ptr(blob), L.ptr(cinit), L.ptr(pa), L.ptr(pb),
+    _launch("sr_wdsr_block_wgrad", L.lib().sr_wdsr_block_wgrad, L.ptr(xs), L.ptr(dys), L.ptr(blob), L.ptr(cinit), L.ptr(pa), L.ptr(pb),
                                         nb, wgs_per_layer, n, h, w, f, L.DTYPE_CODE[xs.dtype],
                                         xs.stride(0), dys.stride(0), blob.stride(0), cinit.stride(0),
-                                        L.stream_ptr()), "sr_wdsr_block_wgrad")
+                                        L.stream_ptr())
     slab = torch.cat([pa.sum(1), pb.sum(1)], dim=1)
     g = slab.index_select(1, tb["grad"])
     return torch.cat([g, g.new_zeros(nb, 2)], dim=1)
@@ -136,20 +168,20 @@ def pack_ends(src_head: torch.Tensor, src_tail: torch.Tensor, F: int, R: int, dt
 
 def head_fwd(x: torch.Tensor, y: torch.Tensor, blob: torch.Tensor, mean: float):
     n, _, h, w = x.shape
-    L.check(L.lib().sr_head_fwd(L.ptr(x), L.ptr(y), L.ptr(blob), mean, n, h, w, y.shape[-1],
-                                L.DTYPE_CODE[y.dtype], L.stream_ptr()), "sr_head_fwd")
+    _launch("sr_head_fwd", L.lib().sr_head_fwd, L.ptr(x), L.ptr(y), L.ptr(blob), mean, n, h, w, y.shape[-1],
+                                L.DTYPE_CODE[y.dtype], L.stream_ptr())
 
 
 def tail_fwd(feat: torch.Tensor, x: torch.Tensor, out: torch.Tensor, blob: torch.Tensor, mean: float, R: int):
     n, h, w, f = feat.shape
-    L.check(L.lib().sr_tail_fwd(L.ptr(feat), L.ptr(x), L.ptr(out), L.ptr(blob), mean, n, h, w, f, R,
-                                L.DTYPE_CODE[feat.dtype], L.stream_ptr()), "sr_tail_fwd")
+    _launch("sr_tail_fwd", L.lib().sr_tail_fwd, L.ptr(feat), L.ptr(x), L.ptr(out), L.ptr(blob), mean, n, h, w, f, R,
+                                L.DTYPE_CODE[feat.dtype], L.stream_ptr())
 
 
 def tail_bwd_data(dout: torch.Tensor, dfeat: torch.Tensor, blob: torch.Tensor, R: int):
     n, h, w, f = dfeat.shape
-    L.check(L.lib().sr_tail_bwd_data(L.ptr(dout), L.ptr(dfeat), L.ptr(blob), n, h, w, f, R,
-                                     L.DTYPE_CODE[dfeat.dtype], L.stream_ptr()), "sr_tail_bwd_data")
+    _launch("sr_tail_bwd_data", L.lib().sr_tail_bwd_data, L.ptr(dout), L.ptr(dfeat), L.ptr(blob), n, h, w, f, R,
+                                     L.DTYPE_CODE[dfeat.dtype], L.stream_ptr())
 
 
 def tail_wgrad(dout: torch.Tensor, feat: torch.Tensor, x: torch.Tensor, mean: float, R: int,
@@ -158,8 +190,8 @@ def tail_wgrad(dout: torch.Tensor, feat: torch.Tensor, x: torch.Tensor, mean: fl
     n, h, w, f = feat.shape
     tb = ends_tables(f, R, feat.device)
     part = torch.empty((wgs, tb["tail_slab"]), dtype=torch.float32, device=feat.device)
-    L.check(L.lib().sr_tail_wgrad(L.ptr(dout), L.ptr(feat), L.ptr(x), mean, L.ptr(part), wgs, n, h, w, f, R,
-                                  L.DTYPE_CODE[feat.dtype], L.stream_ptr()), "sr_tail_wgrad")
+    _launch("sr_tail_wgrad", L.lib().sr_tail_wgrad, L.ptr(dout), L.ptr(feat), L.ptr(x), mean, L.ptr(part), wgs, n, h, w, f, R,
+                                  L.DTYPE_CODE[feat.dtype], L.stream_ptr())
     g = part.sum(0).index_select(0, tb["tail_grad"])
     return torch.cat([g, g.new_zeros(2)])
 
@@ -168,7 +200,7 @@ def head_wgrad(dy0: torch.Tensor, x: torch.Tensor, mean: float, wgs: int = 64) -
     n, h, w, f = dy0.shape
     tb = ends_tables(f, 4, dy0.device)
     part = torch.empty((wgs, tb["head_slab"]), dtype=torch.float32, device=dy0.device)
-    L.check(L.lib().sr_head_wgrad(L.ptr(dy0), L.ptr(x), mean, L.ptr(part), wgs, n, h, w, f,
-                                  L.DTYPE_CODE[dy0.dtype], L.stream_ptr()), "sr_head_wgrad")
+    _launch("sr_head_wgrad", L.lib().sr_head_wgrad, L.ptr(dy0), L.ptr(x), mean, L.ptr(part), wgs, n, h, w, f,
+                                  L.DTYPE_CODE[dy0.dtype], L.stream_ptr())
     g = part.sum(0).index_select(0, tb["head_grad"])
     return torch.cat([g, g.new_zeros(2)])
