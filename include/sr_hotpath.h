@@ -40,6 +40,11 @@ int sr_abi_version(void);
 int sr_wdsr_block_fwd(const void* x, void* y, const void* wblob, const float* cinit,
                       int N, int H, int W, int F, int dtype, sr_stream_t stream);
 
+/* Measurement aid for bench.py's roofline leg: `reps` back-to-back launches of the same forward kernel,
+ * ping-ponging x <-> y, so that HIP events around the call measure the kernel and not the host. */
+int sr_wdsr_block_fwd_repeat(void* x, void* y, const void* wblob, const float* cinit,
+                             int N, int H, int W, int F, int dtype, int reps, sr_stream_t stream);
+
 /* Fused residual block backward w.r.t. its input.  Replaces autograd's backward of Block.forward
  * (models/basic_wdsr_b.py:142-144): dx = dy + W1^T[1(h>0) * W2^T conv3x3^T(dy)], h recomputed from x.
  * wblob / cinit: packing.block_tables() (forward sections first). */
@@ -77,6 +82,47 @@ int sr_tail_wgrad(const float* dout, const void* feat, const float* x_nchw, floa
 /* Weight/bias gradient of the head conv from dy0 = d(loss)/d(head output), NHWC: partial[wgs][3*1024]. */
 int sr_head_wgrad(const void* dy0, const float* x_nchw, float mean, float* partial, int wgs,
                   int N, int H, int W, int F, int dtype, sr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-network entry points: everything BASIC_MODEL.forward (models/basic_wdsr_b.py:85-93) and its
+ * autograd backward do, as ONE call each.  The caller (mobilesuperresolution_amd/models) owns every
+ * buffer; `sr_wdsr_net_t` only carries device pointers, table sizes and the geometry.
+ * Parameters live in one flat fp32 buffer (layout: mobilesuperresolution_amd/layout.py).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int F, NB, R, dtype, N, H, W;
+  float mean;
+  /* parameters, their gradient, weight-norm tables */
+  const float* flat; float* gflat;
+  const int* chan_tab; int n_chan;              /* int4 {v_off, g_off, K, dst_off} per output channel */
+  const int* bias_tab; const float* bias_const; int n_bias;   /* int3 {src_a, src_b, dst} per bias element */
+  /* canonical effective-weight vectors (src) and their gradient (dsrc): head | body[NB] | tail */
+  float* src; float* dsrc;
+  long src_head_off, src_body_off, src_body_stride, src_tail_off;
+  /* fragment packing tables and packed blobs */
+  const int* idx_head; int n_idx_head;
+  const int* idx_body; int n_idx_body;
+  const int* idx_cinit; int n_idx_cinit;
+  const int* idx_tail; int n_idx_tail;
+  void* blob_head; void* blob_body; float* cinit_body; void* blob_tail;
+  /* gradient slabs written by the weight-gradient kernels and their gather tables {slab idx, dst idx} */
+  float* part_a; float* part_b; float* part_tail; float* part_head;
+  int wgs_body, wgs_tail, wgs_head;
+  int slab_a, slab_b, slab_tail, slab_head;
+  const int* ga_sidx; const int* ga_dst; int n_ga;
+  const int* gb_sidx; const int* gb_dst; int n_gb;
+  const int* gt_sidx; const int* gt_dst; int n_gt;
+  const int* gh_sidx; const int* gh_dst; int n_gh;
+  /* activations: x NCHW fp32; acts/grads [(NB+1)][N][H][W][F] (acts may be 2 ping-pong slots when
+   * save_acts == 0); out / dout NCHW fp32 [N][3][R*H][R*W] */
+  const float* x; void* acts; void* grads; float* out; const float* dout;
+} sr_wdsr_net_t;
+
+/* weight-norm + packing + head + NB fused blocks + fused tail.  save_acts != 0 keeps every block input
+ * (needed by sr_wdsr_net_backward); 0 ping-pongs between two slots (inference). */
+int sr_wdsr_net_forward(const sr_wdsr_net_t* net, int save_acts, sr_stream_t stream);
+/* full backward: d(loss)/d(out) -> gflat (gradient of every parameter in the flat buffer). */
+int sr_wdsr_net_backward(const sr_wdsr_net_t* net, sr_stream_t stream);
 
 /* ---- hardware probes used by tests/test_gpu_probe.py (lane maps the kernels rely on) ---- */
 int sr_probe_mfma_bf16(const void* a_frag, const void* b_frag, float* acc_out, sr_stream_t stream);

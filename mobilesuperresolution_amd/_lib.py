@@ -18,6 +18,7 @@ _P, _I, _Z, _L, _F = c_void_p, c_int, c_size_t, ctypes.c_long, ctypes.c_float
 SIGNATURES = {
     "sr_abi_version": ([], _I),
     "sr_wdsr_block_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
+    "sr_wdsr_block_fwd_repeat": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block_bwd_data": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block_wgrad": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P], _I),
     "sr_wdsr_block_slab_sizes": ([_I, _P, _P], _I),
@@ -26,11 +27,30 @@ SIGNATURES = {
     "sr_tail_bwd_data": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_tail_wgrad": ([_P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_head_wgrad": ([_P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P], _I),
+    "sr_wdsr_net_forward": ([_P, _I, _P], _I),
+    "sr_wdsr_net_backward": ([_P, _P], _I),
     "sr_probe_mfma_bf16": ([_P, _P, _P, _P], _I),
     "sr_probe_mfma_f32": ([_P, _P, _P, _P], _I),
     "sr_probe_tr_read": ([_P, _I, _P, _P, _P], _I),
     "sr_probe_copy": ([_P, _P, _Z, _P], _I),
 }
+
+class WdsrNet(ctypes.Structure):
+    """mirror of sr_wdsr_net_t (include/sr_hotpath.h); field order and types must match"""
+    _fields_ = (
+        [(n, _I) for n in ("F", "NB", "R", "dtype", "N", "H", "W")] + [("mean", _F)] +
+        [("flat", _P), ("gflat", _P), ("chan_tab", _P), ("n_chan", _I),
+         ("bias_tab", _P), ("bias_const", _P), ("n_bias", _I), ("src", _P), ("dsrc", _P)] +
+        [(n, _L) for n in ("src_head_off", "src_body_off", "src_body_stride", "src_tail_off")] +
+        [("idx_head", _P), ("n_idx_head", _I), ("idx_body", _P), ("n_idx_body", _I),
+         ("idx_cinit", _P), ("n_idx_cinit", _I), ("idx_tail", _P), ("n_idx_tail", _I),
+         ("blob_head", _P), ("blob_body", _P), ("cinit_body", _P), ("blob_tail", _P),
+         ("part_a", _P), ("part_b", _P), ("part_tail", _P), ("part_head", _P)] +
+        [(n, _I) for n in ("wgs_body", "wgs_tail", "wgs_head", "slab_a", "slab_b", "slab_tail", "slab_head")] +
+        [("ga_sidx", _P), ("ga_dst", _P), ("n_ga", _I), ("gb_sidx", _P), ("gb_dst", _P), ("n_gb", _I),
+         ("gt_sidx", _P), ("gt_dst", _P), ("n_gt", _I), ("gh_sidx", _P), ("gh_dst", _P), ("n_gh", _I),
+         ("x", _P), ("acts", _P), ("grads", _P), ("out", _P), ("dout", _P)])
+
 
 _lib = None
 
@@ -78,3 +98,36 @@ def ptr(t: torch.Tensor) -> int:
     if not t.is_contiguous():
         raise HotpathError("SR hot path needs contiguous tensors")
     return t.data_ptr()
+
+
+class KernelTimer:
+    """Optional per-call timing with HIP events on the launch stream (bench.py's roofline leg).
+    Off by default: the product path records nothing."""
+
+    def __init__(self):
+        self.events = {}
+
+    def run(self, name, fn, *args):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        self.events.setdefault(name, []).append((e0, e1))
+        return rc
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.events.items()}
+
+
+_TIMER = None
+
+
+def set_timer(t):
+    global _TIMER
+    _TIMER = t
+
+
+def launch(name, fn, *args):
+    rc = fn(*args) if _TIMER is None else _TIMER.run(name, fn, *args)
+    check(rc, name)

@@ -1,7 +1,9 @@
 // C-ABI entry points of libsr_hotpath.so (declared in include/sr_hotpath.h).
+#include <algorithm>
 #include "../../include/sr_hotpath.h"
 #include "wdsr_block.h"
 #include "wdsr_ends.h"
+#include "wdsr_prep.h"
 
 extern "C" int sr_abi_version(void) { return 1; }
 
@@ -48,6 +50,16 @@ int launch_block_wgrad(const void* x, const void* dy, const void* wblob, const f
 }
 
 }  // namespace
+
+extern "C" int sr_wdsr_block_fwd_repeat(void* x, void* y, const void* wblob, const float* cinit, int N, int H, int W,
+                                        int F, int dtype, int reps, sr_stream_t stream) {
+  for (int i = 0; i < reps; ++i) {
+    const int rc = (i & 1) ? sr_wdsr_block_fwd(y, x, wblob, cinit, N, H, W, F, dtype, stream)
+                           : sr_wdsr_block_fwd(x, y, wblob, cinit, N, H, W, F, dtype, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
 
 extern "C" int sr_wdsr_block_bwd_data(const void* x, const void* dy, void* dx, const void* wblob,
                                       const float* cinit, int N, int H, int W, int F, int dtype,
@@ -175,6 +187,92 @@ extern "C" int sr_head_wgrad(const void* dy0, const float* x, float mean, float*
     hipLaunchKernelGGL((sr_head_wgrad_kernel<T, F_>), dim3(wgs), dim3(256), 0, st, (const T*)dy0, x, mean, partial, N, H, W, tx, tpi); }
   SR_DISPATCH_TF(CALL)
 #undef CALL
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// whole network
+// ------------------------------------------------------------------------------------------
+namespace {
+template <typename T> int net_pack(const sr_wdsr_net_t* n, hipStream_t st) {
+  const int cb = (n->n_chan + 3) / 4, bb = (n->n_bias + 255) / 256;
+  hipLaunchKernelGGL(wn_src_kernel, dim3(cb + bb), dim3(256), 0, st, n->flat, n->src, (const int4*)n->chan_tab,
+                     n->n_chan, n->bias_tab, n->bias_const, n->n_bias, cb);
+  hipLaunchKernelGGL((pack_kernel<T>), dim3((n->n_idx_head + 255) / 256, 1), dim3(256), 0, st,
+                     n->src + n->src_head_off, n->idx_head, (T*)n->blob_head, n->n_idx_head, 0L);
+  hipLaunchKernelGGL((pack_kernel<T>), dim3(std::min((n->n_idx_body + 255) / 256, 64), n->NB), dim3(256), 0, st,
+                     n->src + n->src_body_off, n->idx_body, (T*)n->blob_body, n->n_idx_body, n->src_body_stride);
+  hipLaunchKernelGGL((pack_kernel<float>), dim3((n->n_idx_cinit + 255) / 256, n->NB), dim3(256), 0, st,
+                     n->src + n->src_body_off, n->idx_cinit, n->cinit_body, n->n_idx_cinit, n->src_body_stride);
+  hipLaunchKernelGGL((pack_kernel<T>), dim3(std::min((n->n_idx_tail + 255) / 256, 64), 1), dim3(256), 0, st,
+                     n->src + n->src_tail_off, n->idx_tail, (T*)n->blob_tail, n->n_idx_tail, 0L);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+}  // namespace
+
+extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int save_acts, sr_stream_t stream) {
+  if (!n || !n->flat || !n->src || !n->x || !n->acts || !n->out) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t esz = n->dtype == SR_DTYPE_BF16 ? 2 : 4;
+  int rc = n->dtype == SR_DTYPE_BF16 ? net_pack<__bf16>(n, st) : net_pack<float>(n, st);
+  if (rc) return rc;
+  const size_t act = (size_t)n->N * n->H * n->W * n->F * esz;
+  const size_t blob = (size_t)n->n_idx_body * esz;
+  char* acts = (char*)n->acts;
+  if ((rc = sr_head_fwd(n->x, acts, n->blob_head, n->mean, n->N, n->H, n->W, n->F, n->dtype, stream))) return rc;
+  char* cur = acts;
+  for (int i = 0; i < n->NB; ++i) {
+    char* nxt = save_acts ? acts + (size_t)(i + 1) * act : (cur == acts ? acts + act : acts);
+    if ((rc = sr_wdsr_block_fwd(cur, nxt, (char*)n->blob_body + i * blob, n->cinit_body + (size_t)i * n->n_idx_cinit,
+                                n->N, n->H, n->W, n->F, n->dtype, stream)))
+      return rc;
+    cur = nxt;
+  }
+  return sr_tail_fwd(cur, n->x, n->out, n->blob_tail, n->mean, n->N, n->H, n->W, n->F, n->R, n->dtype, stream);
+}
+
+extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) {
+  if (!n || !n->flat || !n->gflat || !n->dsrc || !n->x || !n->acts || !n->grads || !n->dout) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t esz = n->dtype == SR_DTYPE_BF16 ? 2 : 4;
+  const size_t act = (size_t)n->N * n->H * n->W * n->F * esz;
+  const size_t blob = (size_t)n->n_idx_body * esz;
+  const long act_e = (long)n->N * n->H * n->W * n->F;
+  char* acts = (char*)n->acts;
+  char* grads = (char*)n->grads;
+  int rc;
+  if ((rc = sr_tail_bwd_data(n->dout, grads + (size_t)n->NB * act, n->blob_tail, n->N, n->H, n->W, n->F, n->R,
+                             n->dtype, stream)))
+    return rc;
+  if ((rc = sr_tail_wgrad(n->dout, acts + (size_t)n->NB * act, n->x, n->mean, n->part_tail, n->wgs_tail, n->N, n->H,
+                          n->W, n->F, n->R, n->dtype, stream)))
+    return rc;
+  for (int i = n->NB - 1; i >= 0; --i)
+    if ((rc = sr_wdsr_block_bwd_data(acts + (size_t)i * act, grads + (size_t)(i + 1) * act, grads + (size_t)i * act,
+                                     (char*)n->blob_body + i * blob, n->cinit_body + (size_t)i * n->n_idx_cinit, n->N,
+                                     n->H, n->W, n->F, n->dtype, stream)))
+      return rc;
+  if ((rc = sr_wdsr_block_wgrad(acts, grads + act, n->blob_body, n->cinit_body, n->part_a, n->part_b, n->NB,
+                                n->wgs_body, n->N, n->H, n->W, n->F, n->dtype, act_e, act_e, (long)n->n_idx_body,
+                                (long)n->n_idx_cinit, stream)))
+    return rc;
+  if ((rc = sr_head_wgrad(grads, n->x, n->mean, n->part_head, n->wgs_head, n->N, n->H, n->W, n->F, n->dtype, stream)))
+    return rc;
+  // slabs -> d(effective weights) -> d(flat parameters)
+  float* d_body = n->dsrc + n->src_body_off;
+  hipLaunchKernelGGL(unpack_sum_kernel, dim3(std::min((n->n_ga + 255) / 256, 32), n->NB), dim3(256), 0, st, n->part_a,
+                     n->wgs_body, (long)n->slab_a, n->ga_sidx, n->ga_dst, d_body, n->n_ga, n->src_body_stride);
+  hipLaunchKernelGGL(unpack_sum_kernel, dim3(std::min((n->n_gb + 255) / 256, 32), n->NB), dim3(256), 0, st, n->part_b,
+                     n->wgs_body, (long)n->slab_b, n->gb_sidx, n->gb_dst, d_body, n->n_gb, n->src_body_stride);
+  hipLaunchKernelGGL(unpack_sum_kernel, dim3((n->n_gt + 255) / 256, 1), dim3(256), 0, st, n->part_tail, n->wgs_tail,
+                     (long)n->slab_tail, n->gt_sidx, n->gt_dst, n->dsrc + n->src_tail_off, n->n_gt, 0L);
+  hipLaunchKernelGGL(unpack_sum_kernel, dim3((n->n_gh + 255) / 256, 1), dim3(256), 0, st, n->part_head, n->wgs_head,
+                     (long)n->slab_head, n->gh_sidx, n->gh_dst, n->dsrc + n->src_head_off, n->n_gh, 0L);
+  const int cb = (n->n_chan + 3) / 4, bb = (n->n_bias + 255) / 256;
+  hipLaunchKernelGGL(wn_bwd_kernel, dim3(cb + bb), dim3(256), 0, st, n->flat, n->dsrc, n->gflat,
+                     (const int4*)n->chan_tab, n->n_chan, n->bias_tab, n->n_bias, cb);
   SR_HIP_CHECK_LAUNCH();
   return 0;
 }

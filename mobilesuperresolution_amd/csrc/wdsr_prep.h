@@ -1,0 +1,95 @@
+// Parameter plumbing kernels: weight-norm (w = g v / ||v||, reference models/basic_wdsr_b.py:23 via
+// torch.nn.utils.weight_norm), fragment packing, and their backward.  They turn the model's single
+// flat fp32 parameter buffer into the packed MFMA fragment blobs the compute kernels read, and the
+// weight-gradient slabs back into a flat gradient, in a handful of tiny launches.
+#pragma once
+#include "sr_common.h"
+
+SR_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// chan_tab[c] = {v_off, g_off, K, dst_off}; one wave per output channel.
+// bias_tab[i] = {src_a, src_b (-1: none), dst}; value = flat[src_a] + flat[src_b] + bias_const[i].
+__global__ __launch_bounds__(256) void wn_src_kernel(const float* __restrict__ flat, float* __restrict__ src,
+                                                     const int4* __restrict__ chan_tab, int n_chan,
+                                                     const int* __restrict__ bias_tab,
+                                                     const float* __restrict__ bias_const, int n_bias,
+                                                     int chan_blocks) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x < chan_blocks) {
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= n_chan) return;
+    const int4 t = chan_tab[c];
+    const float* v = flat + t.x;
+    float ss = 0.f;
+    for (int k = lane; k < t.z; k += 64) { const float a = v[k]; ss += a * a; }
+    ss = wave_sum(ss);
+    const float scale = flat[t.y] / sqrtf(ss);
+    float* d = src + t.w;
+    for (int k = lane; k < t.z; k += 64) d[k] = v[k] * scale;
+  } else {
+    const int i = (blockIdx.x - chan_blocks) * 256 + threadIdx.x;
+    if (i >= n_bias) return;
+    const int a = bias_tab[3 * i], b = bias_tab[3 * i + 1], d = bias_tab[3 * i + 2];
+    src[d] = flat[a] + (b >= 0 ? flat[b] : 0.f) + bias_const[i];
+  }
+}
+
+// out[rep][i] = (T) src[rep * src_stride + idx[i]]
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, const int* __restrict__ idx,
+                                                   T* __restrict__ out, int n, long src_stride) {
+  const int rep = blockIdx.y;
+  const float* s = src + (size_t)rep * src_stride;
+  T* o = out + (size_t)rep * n;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) o[i] = (T)s[idx[i]];
+}
+
+// dsrc[rep * dst_stride + dst[i]] = sum_w partial[(rep * wgs + w) * slab + sidx[i]]
+__global__ __launch_bounds__(256) void unpack_sum_kernel(const float* __restrict__ partial, int wgs, long slab,
+                                                         const int* __restrict__ sidx, const int* __restrict__ dst,
+                                                         float* __restrict__ dsrc, int n, long dst_stride) {
+  const int rep = blockIdx.y;
+  const float* p = partial + (size_t)rep * wgs * slab;
+  float* d = dsrc + (size_t)rep * dst_stride;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int s = sidx[i];
+    float acc = 0.f;
+    for (int w = 0; w < wgs; ++w) acc += p[(size_t)w * slab + s];
+    d[dst[i]] = acc;
+  }
+}
+
+// weight-norm backward: dv = (g/n)(dw - v (v.dw)/n^2), dg = (v.dw)/n; biases copy through
+__global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ flat, const float* __restrict__ dsrc,
+                                                     float* __restrict__ gflat, const int4* __restrict__ chan_tab,
+                                                     int n_chan, const int* __restrict__ bias_tab, int n_bias,
+                                                     int chan_blocks) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x < chan_blocks) {
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= n_chan) return;
+    const int4 t = chan_tab[c];
+    const float* v = flat + t.x;
+    const float* dw = dsrc + t.w;
+    float ss = 0.f, dot = 0.f;
+    for (int k = lane; k < t.z; k += 64) { const float a = v[k]; ss += a * a; dot += a * dw[k]; }
+    ss = wave_sum(ss);
+    dot = wave_sum(dot);
+    const float n = sqrtf(ss), g = flat[t.y];
+    const float s1 = g / n, s2 = dot / ss;
+    float* dv = gflat + t.x;
+    for (int k = lane; k < t.z; k += 64) dv[k] = s1 * (dw[k] - v[k] * s2);
+    if (lane == 0) gflat[t.y] = dot / n;
+  } else {
+    const int i = (blockIdx.x - chan_blocks) * 256 + threadIdx.x;
+    if (i >= n_bias) return;
+    const int a = bias_tab[3 * i], b = bias_tab[3 * i + 1], d = bias_tab[3 * i + 2];
+    const float gval = dsrc[d];
+    gflat[a] = gval;
+    if (b >= 0) gflat[b] = gval;
+  }
+}

@@ -14,37 +14,7 @@ from . import _lib as L
 from . import packing as P
 
 
-class KernelTimer:
-    """Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).
-    Off by default: the product path records nothing."""
-
-    def __init__(self):
-        self.events = {}
-
-    def run(self, name, fn, *args):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        rc = fn(*args)
-        e1.record()
-        self.events.setdefault(name, []).append((e0, e1))
-        return rc
-
-    def summary(self):
-        torch.cuda.synchronize()
-        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.events.items()}
-
-
-_TIMER = None
-
-
-def set_timer(t):
-    global _TIMER
-    _TIMER = t
-
-
-def _launch(name, fn, *args):
-    rc = fn(*args) if _TIMER is None else _TIMER.run(name, fn, *args)
-    L.check(rc, name)
+KernelTimer, set_timer, _launch = L.KernelTimer, L.set_timer, L.launch
 
 
 def block_dims(F: int) -> Tuple[int, int, int]:

@@ -2,26 +2,31 @@
 
 Same constructor fields, forward signature, `.scale` attribute and state_dict keys as the
 reference's BASIC_MODEL (models/basic_wdsr_b.py:16-93): `head.*`, `body.{i}.body.{0,2,3}.*`,
-`tail.*`, `skip.0.*`, each conv stored as `bias`, `weight_g`, `weight_v`.  The arithmetic runs in the
-hand-written HIP kernels of libsr_hotpath.so: one launch for the head conv, one fused launch per
-residual block, one fused launch for tail + skip + PixelShuffle + mean; backward mirrors it.  Only the
-tiny weight-norm algebra (w = g v / ||v||, models/basic_wdsr_b.py:23) stays in PyTorch, so that
-autograd carries the packed weight gradients back to `weight_g` / `weight_v`.
+`tail.*`, `skip.0.*`, each conv stored as `bias`, `weight_g`, `weight_v` (153 keys for 16 blocks).
 
-There is no CPU or ATen fallback: CPU tensors, unsupported widths or a missing library raise.
+MI355X-first design: every parameter lives in ONE flat fp32 buffer (`self.flat`, the only
+nn.Parameter); `state_dict()` / `load_state_dict()` expose and accept the reference's 153 named
+tensors as views into it, so checkpoints interchange with the reference (pretrain.py:222-223,260-267)
+while the optimizer, autograd and DDP each see a single tensor.  `forward` is ONE call into
+libsr_hotpath.so (weight-norm, fragment packing, head conv, N fused residual blocks, fused
+tail + skip + PixelShuffle + mean) and `backward` is one more.  Nothing of the SR arithmetic runs in
+PyTorch and there is no CPU / ATen fallback: CPU tensors, unsupported widths or a missing library raise.
 """
 from __future__ import annotations
 
+import ctypes
 import math
 import os
-from typing import List
+from collections import OrderedDict
 
+import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import hotpath as HP
+from .. import _lib as L
+from ..layout import get_layout
 
-__all__ = ["BASIC_MODEL", "Block"]
+__all__ = ["BASIC_MODEL"]
 
 _DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
 
@@ -33,32 +38,54 @@ def _hot_dtype(params) -> torch.dtype:
     return _DTYPES[str(name).lower()]
 
 
-class _WNConv(nn.Module):
-    """Parameters of one weight-normalised conv, registered as the reference's
-    torch.nn.utils.weight_norm(Conv2d(...)) registers them: bias, weight_g, weight_v."""
+class _DeviceState:
+    """Per-device tables and persistent work buffers of one model instance."""
 
-    def __init__(self, cin: int, cout: int, k: int, g_init: float):
-        super().__init__()
-        conv = nn.Conv2d(cin, cout, k)           # PyTorch-default init of weight_v, as in the reference
-        self.bias = nn.Parameter(torch.zeros(cout))
-        self.weight_g = nn.Parameter(torch.full((cout, 1, 1, 1), float(g_init)))
-        self.weight_v = nn.Parameter(conv.weight.detach().clone())
-
-    def weight(self) -> torch.Tensor:
-        v = self.weight_v
-        return v * (self.weight_g / v.flatten(1).norm(dim=1).view(-1, 1, 1, 1))
-
-
-class Block(nn.Module):
-    """Parameter container of one residual block (reference Block, models/basic_wdsr_b.py:96-144).
-    body[1] is the parameter-free ReLU slot, so the keys are body.0 / body.2 / body.3."""
-
-    def __init__(self, num_residual_units: int, kernel_size: int = 3, res_scale: float = 1.0):
-        super().__init__()
-        f = num_residual_units
-        e, l = int(f * 6), int(f * 0.84)
-        self.body = nn.ModuleList([_WNConv(f, e, 1, 2.0), nn.Identity(), _WNConv(e, l, 1, 2.0),
-                                   _WNConv(l, f, kernel_size, res_scale)])
+    def __init__(self, model: "BASIC_MODEL", device: torch.device):
+        lay = model.layout
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        f32 = lambda n: torch.empty(n, dtype=torch.float32, device=device)
+        self.chan_tab, self.bias_tab = t(lay.chan_tab), t(lay.bias_tab)
+        bc = lay.bias_const.copy()
+        bc[np.isnan(bc)] = model.image_mean
+        self.bias_const = t(bc)
+        self.idx = {k: t(getattr(lay, "idx_" + k)) for k in ("head", "body", "cinit", "tail")}
+        self.g = {k: (t(getattr(lay, k)[0]), t(getattr(lay, k)[1])) for k in ("ga", "gb", "gt", "gh")}
+        self.src = torch.zeros(lay.src_total, dtype=torch.float32, device=device)
+        self.src[torch.from_numpy(lay.src_ones).to(device)] = 1.0
+        self.dsrc = torch.zeros(lay.src_total, dtype=torch.float32, device=device)
+        dt = model.hot_dtype
+        self.blob_head = torch.empty(lay.idx_head.size, dtype=dt, device=device)
+        self.blob_body = torch.empty((lay.NB, lay.idx_body.size), dtype=dt, device=device)
+        self.cinit_body = torch.empty((lay.NB, lay.idx_cinit.size), dtype=torch.float32, device=device)
+        self.blob_tail = torch.empty(lay.idx_tail.size, dtype=dt, device=device)
+        self.wgs_body, self.wgs_tail, self.wgs_head = model.wgs_body, 64, 64
+        self.part_a = f32(lay.NB * self.wgs_body * lay.slab_a)
+        self.part_b = f32(lay.NB * self.wgs_body * lay.slab_b)
+        self.part_tail = f32(self.wgs_tail * lay.slab_tail)
+        self.part_head = f32(self.wgs_head * lay.slab_head)
+        # static part of the C struct
+        n = L.WdsrNet()
+        n.F, n.NB, n.R, n.dtype, n.mean = lay.F, lay.NB, lay.R, L.DTYPE_CODE[dt], model.image_mean
+        n.chan_tab, n.n_chan = self.chan_tab.data_ptr(), lay.chan_tab.shape[0]
+        n.bias_tab, n.bias_const, n.n_bias = self.bias_tab.data_ptr(), self.bias_const.data_ptr(), lay.bias_tab.shape[0]
+        n.src, n.dsrc = self.src.data_ptr(), self.dsrc.data_ptr()
+        n.src_head_off, n.src_body_off = lay.src_head_off, lay.src_body_off
+        n.src_body_stride, n.src_tail_off = lay.src_body_stride, lay.src_tail_off
+        for k in ("head", "body", "cinit", "tail"):
+            setattr(n, "idx_" + k, self.idx[k].data_ptr())
+            setattr(n, "n_idx_" + k, self.idx[k].numel())
+        n.blob_head, n.blob_body = self.blob_head.data_ptr(), self.blob_body.data_ptr()
+        n.cinit_body, n.blob_tail = self.cinit_body.data_ptr(), self.blob_tail.data_ptr()
+        n.part_a, n.part_b = self.part_a.data_ptr(), self.part_b.data_ptr()
+        n.part_tail, n.part_head = self.part_tail.data_ptr(), self.part_head.data_ptr()
+        n.wgs_body, n.wgs_tail, n.wgs_head = self.wgs_body, self.wgs_tail, self.wgs_head
+        n.slab_a, n.slab_b, n.slab_tail, n.slab_head = lay.slab_a, lay.slab_b, lay.slab_tail, lay.slab_head
+        for k in ("ga", "gb", "gt", "gh"):
+            setattr(n, k + "_sidx", self.g[k][0].data_ptr())
+            setattr(n, k + "_dst", self.g[k][1].data_ptr())
+            setattr(n, "n_" + k, self.g[k][0].numel())
+        self.net = n
 
 
 class BASIC_MODEL(nn.Module):
@@ -70,100 +97,124 @@ class BASIC_MODEL(nn.Module):
         self.remain_blocks = params.num_blocks
         nin = int(params.num_channels)
         f = int(params.num_residual_units)
-        self.num_residual_units = f
-        if nin != 3 or f not in (24, 32) or self.scale not in (2, 3, 4):
+        nb = int(params.num_blocks)
+        self.num_residual_units, self.num_blocks = f, nb
+        if nin != 3 or f not in (24, 32) or self.scale not in (2, 3, 4) or nb < 1:
             raise NotImplementedError(
                 "MI355X hot path supports num_channels=3, num_residual_units in {24,32}, scale in {2,3,4} "
                 f"(got {nin}, {f}, {self.scale}); there is no generic fallback")
-        nout = self.scale * self.scale * nin
         self.hot_dtype = _hot_dtype(params)
-        self.head = _WNConv(nin, f, 3, 1.0)
-        self.body = nn.ModuleList([Block(f, 3, 1 / math.sqrt(params.num_blocks)) for _ in range(params.num_blocks)])
-        self.tail = _WNConv(f, nout, 3, 1.0)
-        self.skip = nn.ModuleList([_WNConv(nin, nout, 5, 1.0)])     # key skip.0.*, as nn.Sequential in the reference
-        self.shuf = nn.Sequential()                                  # parameter-free; the shuffle is fused
+        self.wgs_body = int(getattr(params, "hot_wgs_body", 16))
+        self.layout = get_layout(f, nb, self.scale)
+        self.flat = nn.Parameter(self._reference_init())
+        self._dev = {}
 
-    # ---- canonical (effective-weight) source vectors, differentiable w.r.t. the parameters ----
-    def _sources(self):
-        mean = self.image_mean
-        src_head = HP.head_src(self.head.weight(), self.head.bias)
-        btot = self.tail.bias + self.skip[0].bias + mean
-        src_tail = HP.tail_src(self.tail.weight(), self.skip[0].weight(), btot)
-        convs = [[blk.body[i] for blk in self.body] for i in (0, 2, 3)]
-        ws, bs = [], []
-        for layer in convs:
-            v = torch.stack([c.weight_v for c in layer])
-            g = torch.stack([c.weight_g for c in layer])
-            ws.append(v * (g / v.flatten(2).norm(dim=2).view(v.shape[0], v.shape[1], 1, 1, 1)))
-            bs.append(torch.stack([c.bias for c in layer]))
-        src_body = HP.block_src(ws[0], ws[1], ws[2], bs[0], bs[1], bs[2])
-        return src_head, src_body, src_tail
+    # ---- initial values exactly as the reference constructs them (same RNG draws, same constants) ----
+    def _reference_init(self) -> torch.Tensor:
+        lay = self.layout
+        flat = torch.zeros(lay.total)
+        gains = {"head": 1.0, "tail": 1.0, "skip.0": 1.0}
+        for i in range(lay.NB):
+            gains[f"body.{i}.body.0"] = 2.0                      # basic_wdsr_b.py:115
+            gains[f"body.{i}.body.2"] = 2.0                      # :126
+            gains[f"body.{i}.body.3"] = 1 / math.sqrt(lay.NB)    # :136 (res_scale only seeds weight_g)
+        for c in lay.convs:
+            conv = nn.Conv2d(c.cin, c.cout, c.k)                 # PyTorch-default init of weight_v (and a bias draw)
+            off, shape = lay.entries[c.name + ".weight_v"]
+            flat[off:off + conv.weight.numel()] = conv.weight.detach().reshape(-1)
+            off, _ = lay.entries[c.name + ".weight_g"]
+            flat[off:off + c.cout] = gains[c.name]
+        return flat                                             # biases stay 0 (:41,63,76,116,127,137)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if not x.is_cuda:
-            raise HP.L.HotpathError("BASIC_MODEL (MI355X hot path) needs a CUDA/HIP tensor; there is no CPU fallback")
+    # ---- reference-compatible checkpoints ----
+    def named_tensors(self):
+        """(reference key, view into the flat parameter) for all 3 x (3*num_blocks + 3) tensors"""
+        for name, (off, shape) in self.layout.entries.items():
+            yield name, self.flat.detach()[off:off + int(np.prod(shape))].view(shape)
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        if destination is None:
+            destination = OrderedDict()
+        for name, view in self.named_tensors():
+            destination[prefix + name] = view
+        return destination
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        with torch.no_grad():
+            for name, view in self.named_tensors():
+                key = prefix + name
+                if key not in state_dict:
+                    missing_keys.append(key)
+                    continue
+                src = state_dict[key]
+                if tuple(src.shape) != tuple(view.shape):
+                    error_msgs.append(f"size mismatch for {key}: checkpoint {tuple(src.shape)} vs model {tuple(view.shape)}")
+                    continue
+                view.copy_(src)
+        known = {prefix + n for n in self.layout.entries}
+        for key in state_dict:
+            if key.startswith(prefix) and key not in known and key != prefix + "flat":
+                unexpected_keys.append(key)
+
+    # ---- execution ----
+    def _state(self, device: torch.device) -> _DeviceState:
+        key = (device.type, device.index)
+        st = self._dev.get(key)
+        if st is None or st.blob_head.dtype != self.hot_dtype:
+            st = self._dev[key] = _DeviceState(self, device)
+        return st
+
+    def _check_input(self, x):
+        if not x.is_cuda or not self.flat.is_cuda:
+            raise L.HotpathError("BASIC_MODEL (MI355X hot path) needs CUDA/HIP tensors; there is no CPU fallback")
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError(f"expected N x 3 x H x W input, got {tuple(x.shape)}")
-        x = x.contiguous().float()
-        src_head, src_body, src_tail = self._sources()
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if x.requires_grad:
             raise NotImplementedError("gradient w.r.t. the input image is not on the hot path "
                                       "(the reference trainers never request it)")
-        cfg = (self.hot_dtype, self.num_residual_units, self.scale, self.image_mean)
-        if need_grad:
-            return _WDSRFunction.apply(x, src_head, src_body, src_tail, cfg)
-        return _wdsr_infer(x, src_head, src_body, src_tail, cfg)
+
+    def _forward_impl(self, x, flat, save_acts: bool):
+        st = self._state(x.device)
+        lay = self.layout
+        n, _, h, w = x.shape
+        slots = lay.NB + 1 if save_acts else 2
+        acts = torch.empty((slots, n, h, w, lay.F), dtype=self.hot_dtype, device=x.device)
+        out = torch.empty((n, 3, self.scale * h, self.scale * w), dtype=torch.float32, device=x.device)
+        net = st.net
+        net.N, net.H, net.W = n, h, w
+        net.flat, net.x, net.acts, net.out = flat.data_ptr(), x.data_ptr(), acts.data_ptr(), out.data_ptr()
+        L.launch("sr_wdsr_net_forward", L.lib().sr_wdsr_net_forward, ctypes.byref(net), int(save_acts), L.stream_ptr())
+        return out, acts
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self._check_input(x)
+        x = x.contiguous().float()
+        if torch.is_grad_enabled() and self.flat.requires_grad:
+            return _NetFunction.apply(x, self.flat, self)
+        return self._forward_impl(x, self.flat.detach(), False)[0]
 
 
-def _wdsr_infer(x, src_head, src_body, src_tail, cfg):
-    dtype, f, r, mean = cfg
-    n, _, h, w = x.shape
-    blob_h, blob_t = HP.pack_ends(src_head, src_tail, f, r, dtype)
-    blob_b, cinit_b = HP.pack_blocks(src_body, f, dtype)
-    a = torch.empty((n, h, w, f), dtype=dtype, device=x.device)
-    b = torch.empty_like(a)
-    HP.head_fwd(x, a, blob_h, mean)
-    for i in range(src_body.shape[0]):
-        HP.block_fwd(a, b, blob_b[i], cinit_b[i])
-        a, b = b, a
-    out = torch.empty((n, 3, r * h, r * w), dtype=torch.float32, device=x.device)
-    HP.tail_fwd(a, x, out, blob_t, mean, r)
-    return out
-
-
-class _WDSRFunction(torch.autograd.Function):
-    """Whole-network forward/backward on the HIP kernels.  Saves the block inputs (bf16 or fp32 NHWC);
-    the E-wide and L-wide intermediates are recomputed in backward, never stored."""
+class _NetFunction(torch.autograd.Function):
+    """Whole-network forward/backward in two C calls.  Saves the block inputs (bf16 or fp32 NHWC); the
+    E-wide and L-wide intermediates are recomputed in backward, never stored."""
 
     @staticmethod
-    def forward(ctx, x, src_head, src_body, src_tail, cfg):
-        dtype, f, r, mean = cfg
-        n, _, h, w = x.shape
-        nb = src_body.shape[0]
-        blob_h, blob_t = HP.pack_ends(src_head, src_tail, f, r, dtype)
-        blob_b, cinit_b = HP.pack_blocks(src_body, f, dtype)
-        acts = torch.empty((nb + 1, n, h, w, f), dtype=dtype, device=x.device)
-        HP.head_fwd(x, acts[0], blob_h, mean)
-        for i in range(nb):
-            HP.block_fwd(acts[i], acts[i + 1], blob_b[i], cinit_b[i])
-        out = torch.empty((n, 3, r * h, r * w), dtype=torch.float32, device=x.device)
-        HP.tail_fwd(acts[nb], x, out, blob_t, mean, r)
-        ctx.save_for_backward(x, acts, blob_b, cinit_b, blob_t)
-        ctx.cfg = cfg
+    def forward(ctx, x, flat, model):
+        out, acts = model._forward_impl(x, flat, True)
+        ctx.model, ctx.x, ctx.acts, ctx.flat = model, x, acts, flat
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, acts, blob_b, cinit_b, blob_t = ctx.saved_tensors
-        dtype, f, r, mean = ctx.cfg
-        nb = blob_b.shape[0]
+        model, x, acts, flat = ctx.model, ctx.x, ctx.acts, ctx.flat
+        st = model._state(x.device)
         dout = dout.contiguous().float()
-        grads = torch.empty_like(acts)                # grads[i] = dL/d acts[i]
-        HP.tail_bwd_data(dout, grads[nb], blob_t, r)
-        d_tail = HP.tail_wgrad(dout, acts[nb], x, mean, r)
-        for i in range(nb - 1, -1, -1):
-            HP.block_bwd_data(acts[i], grads[i + 1], grads[i], blob_b[i], cinit_b[i])
-        d_body = HP.block_wgrad(acts[:nb], grads[1:], blob_b, cinit_b)
-        d_head = HP.head_wgrad(grads[0], x, mean)
-        return None, d_head, d_body, d_tail, None
+        grads = torch.empty_like(acts)
+        gflat = torch.empty_like(flat)
+        net = st.net
+        net.N, net.H, net.W = x.shape[0], x.shape[2], x.shape[3]
+        net.flat, net.gflat, net.x = flat.data_ptr(), gflat.data_ptr(), x.data_ptr()
+        net.acts, net.grads, net.dout = acts.data_ptr(), grads.data_ptr(), dout.data_ptr()
+        L.launch("sr_wdsr_net_backward", L.lib().sr_wdsr_net_backward, ctypes.byref(net), L.stream_ptr())
+        return None, gflat, None

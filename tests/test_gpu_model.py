@@ -49,9 +49,12 @@ def test_g1_fp32_forward_backward_matches_reference(golden_dir):
     assert abs(loss.item() - d["loss"].item()) <= 1e-5 * abs(d["loss"].item())
     loss.backward()
     worst = 0.0
-    for k, p in m.named_parameters():
+    gflat = m.flat.grad.cpu()
+    assert [n for n, _ in m.named_parameters()] == ["flat"]
+    for k, (off, shape) in m.layout.entries.items():
         exp = d["g/" + k]
-        e = (p.grad.cpu() - exp).abs().max().item() / max(exp.abs().max().item(), 1e-12)
+        got = gflat[off:off + exp.numel()].view(shape)
+        e = (got - exp).abs().max().item() / max(exp.abs().max().item(), 1e-12)
         worst = max(worst, e)
         assert e <= 2e-4, (k, e)
     print(f"G1 bwd worst relative grad error {worst:.2e}")
