@@ -14,7 +14,7 @@ int launch_block_fwd(const void* x, void* y, const void* wblob, const float* cin
                      hipStream_t st) {
   typedef BlockCfg<F, E, L> C;
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
-  dim3 grid(tiles_x * tiles_y, N), block(256);
+  dim3 grid(tiles_x * tiles_y, N), block(64 * C::NPT_H);
   hipLaunchKernelGGL((wdsr_block_fwd_kernel<T, F, E, L>), grid, block, 0, st, (const T*)x, (T*)y, (const T*)wblob,
                      cinit, H, W, tiles_x);
   SR_HIP_CHECK_LAUNCH();
@@ -26,7 +26,7 @@ int launch_block_bwd_data(const void* x, const void* dy, void* dx, const void* w
                           int H, int W, hipStream_t st) {
   typedef BlockCfg<F, E, L> C;
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
-  dim3 grid(tiles_x * tiles_y, N), block(256);
+  dim3 grid(tiles_x * tiles_y, N), block(64 * C::NPT_O);
   hipLaunchKernelGGL((wdsr_block_bwd_data_kernel<T, F, E, L>), grid, block, 0, st, (const T*)x, (const T*)dy, (T*)dx,
                      (const T*)wblob, cinit, H, W, tiles_x);
   SR_HIP_CHECK_LAUNCH();
@@ -39,12 +39,13 @@ int launch_block_wgrad(const void* x, const void* dy, const void* wblob, const f
                        hipStream_t st) {
   typedef BlockCfg<F, E, L> C;
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
-  dim3 grid(wgs, layers), block(256);
-  hipLaunchKernelGGL((wdsr_block_wgrad12_kernel<T, F, E, L>), grid, block, 0, st, (const T*)x, (const T*)dy,
-                     (const T*)wblob, cinit, pa, N, H, W, tiles_x, tiles_x * tiles_y, x_ls, dy_ls, w_ls, c_ls);
-  SR_HIP_CHECK_LAUNCH();
-  hipLaunchKernelGGL((wdsr_block_wgrad3_kernel<T, F, E, L>), grid, block, 0, st, (const T*)x, (const T*)dy,
-                     (const T*)wblob, cinit, pb, N, H, W, tiles_x, tiles_x * tiles_y, x_ls, dy_ls, w_ls, c_ls);
+  dim3 grid(wgs, layers);
+  hipLaunchKernelGGL((wdsr_block_wgrad_kernel<T, F, E, L, 0>), grid, dim3(64 * WgradCfg<F, E, L, 0>::NWAVES), 0, st,
+                     (const T*)x, (const T*)dy, (const T*)wblob, cinit, pa, N, H, W, tiles_x, tiles_x * tiles_y, x_ls,
+                     dy_ls, w_ls, c_ls);
+  hipLaunchKernelGGL((wdsr_block_wgrad_kernel<T, F, E, L, 1>), grid, dim3(64 * WgradCfg<F, E, L, 1>::NWAVES), 0, st,
+                     (const T*)x, (const T*)dy, (const T*)wblob, cinit, pb, N, H, W, tiles_x, tiles_x * tiles_y, x_ls,
+                     dy_ls, w_ls, c_ls);
   SR_HIP_CHECK_LAUNCH();
   return 0;
 }

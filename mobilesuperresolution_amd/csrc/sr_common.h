@@ -95,6 +95,31 @@ template <bool HOIST, typename T> SR_DEV const T* weights_for_tile(const T* w) {
   }
 }
 
+// Where a kernel's packed weight fragments come from: an LDS copy staged once per workgroup (bf16 mode:
+// one conflict-free ds_read_b128 per fragment) or global memory (fp32 parity mode: the fragments are
+// twice as large and speed is not the point), re-laundered per tile so the loads are never hoisted.
+template <typename T, bool INLDS> struct WSrc;
+template <typename T> struct WSrc<T, true> {
+  const T* p;
+  SR_DEV void tile() {}
+  SR_DEV typename FragOf<T>::type get(int idx, int lane) const {
+    return *reinterpret_cast<const typename FragOf<T>::type*>(p + (idx * 64 + lane) * 8);
+  }
+};
+template <typename T> struct WSrc<T, false> {
+  const T* p0;
+  const T* p;
+  SR_DEV void tile() { p = weights_for_tile<false>(p0); }
+  SR_DEV typename FragOf<T>::type get(int idx, int lane) const { return load_wfrag<T>(p, idx, lane); }
+};
+
+// copy `nfrag` packed fragments (512 elements each) global -> LDS with all threads of the workgroup
+template <typename T, int NTHREADS> SR_DEV void stage_weights(T* dst, const T* __restrict__ src, int nfrag, int tid) {
+  typedef typename FragOf<T>::type FragT;
+  for (int i = tid; i < nfrag * 64; i += NTHREADS)
+    *reinterpret_cast<FragT*>(dst + i * 8) = *reinterpret_cast<const FragT*>(src + (size_t)i * 8);
+}
+
 // 8 consecutive elements from an LDS image (16-byte aligned element offset)
 template <typename T> SR_DEV typename FragOf<T>::type lds_chunk(const T* img, int elem_off) {
   return *reinterpret_cast<const typename FragOf<T>::type*>(img + elem_off);

@@ -29,61 +29,77 @@ struct BlockCfg {
   static constexpr int CINIT_FWD = 32 + (FOLD_B1 ? 0 : NET * 32);
 };
 
-// stage the halo'd x tile [NPXH_PAD][KX] into LDS: zero outside the image, ones channel at index F
-template <typename T, typename C>
+// stage the halo'd x tile [NPXH_PAD][KX] into LDS: zero outside the image, ones channel at index F.
+// All global loads are issued before the first LDS store (one HBM round trip, not one per chunk).
+template <typename T, typename C, int NTHREADS>
 SR_DEV void stage_x_halo(T* Xs, const T* __restrict__ xin, int H, int W, int ty0, int tx0, int tid) {
   typedef typename FragOf<T>::type FragT;
-  constexpr int CHX = C::KX / 8;
-  for (int idx = tid; idx < C::NPXH_PAD * CHX; idx += 256) {
-    const int hp = idx / CHX, c = idx - hp * CHX;
-    FragT v;
+  constexpr int CHX = C::KX / 8, TOTAL = C::NPXH_PAD * CHX, ITER = (TOTAL + NTHREADS - 1) / NTHREADS;
+  FragT v[ITER];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (T)0.f;
-    if (c < C::FC) {
-      if (hp < C::NPXH) {
-        const int hy = hp / C::HW, hx = hp - hy * C::HW;
-        const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
-        if (Y >= 0 && Y < H && X >= 0 && X < W)
-          v = *reinterpret_cast<const FragT*>(xin + ((size_t)Y * W + X) * C::F + c * 8);
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = tid + it * NTHREADS;
+    const int hp = idx / CHX, c = idx - hp * CHX;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[it][j] = (T)0.f;
+    if (idx < TOTAL) {
+      if (c < C::FC) {
+        if (hp < C::NPXH) {
+          const int hy = hp / C::HW, hx = hp - hy * C::HW;
+          const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
+          if (Y >= 0 && Y < H && X >= 0 && X < W)
+            v[it] = *reinterpret_cast<const FragT*>(xin + ((size_t)Y * W + X) * C::F + c * 8);
+        }
+      } else if (C::FOLD_B1 && c == C::FC) {
+        v[it][0] = (T)1.f;
       }
-    } else if (C::FOLD_B1 && c == C::FC) {
-      v[0] = (T)1.f;
     }
-    *reinterpret_cast<FragT*>(Xs + hp * C::KX + c * 8) = v;
+  }
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = tid + it * NTHREADS;
+    if (idx < TOTAL) *reinterpret_cast<FragT*>(Xs + idx * 8) = v[it];
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // forward:  y = conv3x3(W3, conv1x1(W2, relu(conv1x1(W1, x) + b1)) + b2) + b3 + x
-// grid = (tiles_y * tiles_x, N), block = 256 (4 waves, one per SIMD)
+// grid = (tiles_y * tiles_x, N); one wave per 32-pixel tile of the halo'd region (NPT_H waves).
 // ---------------------------------------------------------------------------------------------
 template <typename T, int F, int E, int L>
-__global__ __launch_bounds__(256) void wdsr_block_fwd_kernel(
+__global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block_fwd_kernel(
     const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ wblob,
     const float* __restrict__ cinit, int H, int W, int tiles_x) {
   typedef BlockCfg<F, E, L> C;
   typedef typename FragOf<T>::type FragT;
   typedef typename FragOf<T>::half_type HalfT;
-  // one LDS array (x tile, then t tile) so that every fragment address is an offset into it
-  __shared__ __attribute__((aligned(16))) T smem[C::NPXH_PAD * (C::KX + C::LP)];
+  constexpr int NTHREADS = 64 * C::NPT_H;
+  constexpr bool WLDS = (sizeof(T) == 2);
+  constexpr int TS0 = C::NPXH_PAD * C::KX, W0 = C::NPXH_PAD * (C::KX + C::LP);
+  // one LDS array (x tile, t tile, packed weights) so that every fragment address is an offset into it
+  __shared__ __attribute__((aligned(16))) T smem[W0 + (WLDS ? C::NFRAG_FWD * 512 : 8)];
   T* const Xs = smem;
-  T* const Ts = smem + C::NPXH_PAD * C::KX;
-  constexpr int TS0 = C::NPXH_PAD * C::KX;
+  T* const Ts = smem + TS0;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int n = blockIdx.y, tile = blockIdx.x;
   const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
   const T* xin = x + (size_t)n * H * W * F;
 
-  stage_x_halo<T, C>(Xs, xin, H, W, ty0, tx0, tid);
+  WSrc<T, WLDS> wsrc;
+  if constexpr (WLDS) {
+    stage_weights<T, NTHREADS>(smem + W0, wblob, C::NFRAG_FWD, tid);
+    wsrc.p = smem + W0;
+  } else {
+    wsrc.p0 = wblob;
+  }
+  stage_x_halo<T, C, NTHREADS>(Xs, xin, H, W, ty0, tx0, tid);
   __syncthreads();
 
   // ---- phase A: t = W2 relu(W1 x + b1) + b2 on every halo'd pixel (zero outside the image) ----
-  constexpr bool HOIST = (sizeof(T) == 2);   // bf16 fragments fit in registers; fp32 ones do not
-  const T* const wblob0 = wblob;
-  for (int pt = wave; pt < C::NPT_H; pt += 4) {
-    wblob = weights_for_tile<HOIST>(wblob0);
-    const int hp = pt * 32 + r;
+  {
+    wsrc.tile();
+    const int hp = wave * 32 + r;
     FragT xb[C::KS1];
 #pragma unroll
     for (int s = 0; s < C::KS1; ++s) xb[s] = lds_chunk<T>(Xs, hp * C::KX + (2 * s + hh) * 8);
@@ -92,14 +108,11 @@ __global__ __launch_bounds__(256) void wdsr_block_fwd_kernel(
     for (int et = 0; et < C::NET; ++et) {
       f32x16 hacc = C::FOLD_B1 ? zero16() : load_cinit(cinit + 32 + et * 32, hh);
 #pragma unroll
-      for (int s = 0; s < C::KS1; ++s)
-        hacc = mma16<T>(load_wfrag<T>(wblob, C::W1_OFF + et * C::KS1 + s, lane), xb[s], hacc);
+      for (int s = 0; s < C::KS1; ++s) hacc = mma16<T>(wsrc.get(C::W1_OFF + et * C::KS1 + s, lane), xb[s], hacc);
 #pragma unroll
       for (int i = 0; i < 16; ++i) hacc[i] = fmaxf(hacc[i], 0.f);
-      if (2 * et < C::KS2)
-        tacc = mma16<T>(load_wfrag<T>(wblob, C::W2_OFF + 2 * et, lane), acc_to_frag<T, 0>(hacc), tacc);
-      if (2 * et + 1 < C::KS2)
-        tacc = mma16<T>(load_wfrag<T>(wblob, C::W2_OFF + 2 * et + 1, lane), acc_to_frag<T, 1>(hacc), tacc);
+      if (2 * et < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * et, lane), acc_to_frag<T, 0>(hacc), tacc);
+      if (2 * et + 1 < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * et + 1, lane), acc_to_frag<T, 1>(hacc), tacc);
     }
     bool valid = false;
     if (hp < C::NPXH) {
@@ -120,8 +133,9 @@ __global__ __launch_bounds__(256) void wdsr_block_fwd_kernel(
   __syncthreads();
 
   // ---- phase B: y = sum_taps W3_tap t(shifted) + b3 (ones channel) + x (identity chunks) ----
-  for (int ot = wave; ot < C::NPT_O; ot += 4) {
-    wblob = weights_for_tile<HOIST>(wblob0);
+  if (wave < C::NPT_O) {
+    wsrc.tile();
+    const int ot = wave;
     const int oy = (ot / (C::TW / 8)) * 4 + (r >> 3), ox = (ot % (C::TW / 8)) * 8 + (r & 7);
     const int hbase = oy * C::HW + ox;
     f32x16 oacc = zero16();
@@ -137,8 +151,7 @@ __global__ __launch_bounds__(256) void wdsr_block_fwd_kernel(
         if (c >= C::FC) c = 0;  // weights there are zero; any finite data will do
         off = (hbase + C::HW + 1) * C::KX + c * 8;
       }
-      FragT b = lds_chunk<T>(smem, off);
-      oacc = mma16<T>(load_wfrag<T>(wblob, C::W3_OFF + s, lane), b, oacc);
+      oacc = mma16<T>(wsrc.get(C::W3_OFF + s, lane), lds_chunk<T>(smem, off), oacc);
     }
     const int Y = ty0 + oy, X = tx0 + ox;
     if (Y < H && X < W) {
@@ -168,52 +181,74 @@ template <typename C> struct BwdCfg {
   static constexpr int SLAB_B = 9 * 1024;
 };
 
-template <typename T, typename C>
-SR_DEV void stage_dy_halo(T* DYs, const T* __restrict__ din, int H, int W, int ty0, int tx0, int tid) {
+// backward tiles: dy with a 1-pixel halo [NPXH_PAD + 2][F] and the core x tile [NPXC + 1][KX]; every
+// global load of both is issued before the first LDS store.
+template <typename T, typename C, int NTHREADS>
+SR_DEV void stage_bwd_tiles(T* DYs, T* XC, const T* __restrict__ din, const T* __restrict__ xin, int H, int W,
+                            int ty0, int tx0, int tid) {
   typedef typename FragOf<T>::type FragT;
-  for (int idx = tid; idx < (C::NPXH_PAD + 2) * C::FC; idx += 256) {
-    const int hp = idx / C::FC, c = idx - hp * C::FC;
-    FragT v;
+  constexpr int CHX = C::KX / 8, NPXC = C::TH * C::TW;
+  constexpr int TD = (C::NPXH_PAD + 2) * C::FC, TX = (NPXC + 1) * CHX;
+  constexpr int ID = (TD + NTHREADS - 1) / NTHREADS, IX = (TX + NTHREADS - 1) / NTHREADS;
+  FragT vd[ID], vx[IX];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (T)0.f;
-    if (hp < C::NPXH) {
+  for (int it = 0; it < ID; ++it) {
+    const int idx = tid + it * NTHREADS;
+    const int hp = idx / C::FC, c = idx - hp * C::FC;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vd[it][j] = (T)0.f;
+    if (idx < TD && hp < C::NPXH) {
       const int hy = hp / C::HW, hx = hp - hy * C::HW;
       const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
       if (Y >= 0 && Y < H && X >= 0 && X < W)
-        v = *reinterpret_cast<const FragT*>(din + ((size_t)Y * W + X) * C::F + c * 8);
+        vd[it] = *reinterpret_cast<const FragT*>(din + ((size_t)Y * W + X) * C::F + c * 8);
     }
-    *reinterpret_cast<FragT*>(DYs + hp * C::F + c * 8) = v;
   }
-}
-
-template <typename T, typename C>
-SR_DEV void stage_x_core(T* XC, const T* __restrict__ xin, int H, int W, int ty0, int tx0, int tid) {
-  typedef typename FragOf<T>::type FragT;
-  constexpr int CHX = C::KX / 8, NPXC = C::TH * C::TW;
-  for (int idx = tid; idx < (NPXC + 1) * CHX; idx += 256) {
-    const int pc = idx / CHX, c = idx - pc * CHX;
-    FragT v;
+  if constexpr (sizeof(T) == 4) {   // fp32 parity mode: retire the dy registers before loading x (register budget)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (T)0.f;
-    if (c < C::FC) {
-      if (pc < NPXC) {
-        const int Y = ty0 + pc / C::TW, X = tx0 + pc % C::TW;
-        if (Y < H && X < W) v = *reinterpret_cast<const FragT*>(xin + ((size_t)Y * W + X) * C::F + c * 8);
-      }
-    } else if (C::FOLD_B1 && c == C::FC) {
-      v[0] = (T)1.f;
+    for (int it = 0; it < ID; ++it) {
+      const int idx = tid + it * NTHREADS;
+      if (idx < TD) *reinterpret_cast<FragT*>(DYs + idx * 8) = vd[it];
     }
-    *reinterpret_cast<FragT*>(XC + pc * C::KX + c * 8) = v;
+  }
+#pragma unroll
+  for (int it = 0; it < IX; ++it) {
+    const int idx = tid + it * NTHREADS;
+    const int pc = idx / CHX, c = idx - pc * CHX;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vx[it][j] = (T)0.f;
+    if (idx < TX) {
+      if (c < C::FC) {
+        if (pc < NPXC) {
+          const int Y = ty0 + pc / C::TW, X = tx0 + pc % C::TW;
+          if (Y < H && X < W) vx[it] = *reinterpret_cast<const FragT*>(xin + ((size_t)Y * W + X) * C::F + c * 8);
+        }
+      } else if (C::FOLD_B1 && c == C::FC) {
+        vx[it][0] = (T)1.f;
+      }
+    }
+  }
+  if constexpr (sizeof(T) != 4) {
+#pragma unroll
+    for (int it = 0; it < ID; ++it) {
+      const int idx = tid + it * NTHREADS;
+      if (idx < TD) *reinterpret_cast<FragT*>(DYs + idx * 8) = vd[it];
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < IX; ++it) {
+    const int idx = tid + it * NTHREADS;
+    if (idx < TX) *reinterpret_cast<FragT*>(XC + idx * 8) = vx[it];
   }
 }
 
 // dt^T[l, px] = sum_{u,f} W3[f,l,8-u] dy[px + u - 1, f]   (rows l in regs, pixels on lanes)
-template <typename T, typename C>
-SR_DEV f32x16 dt_tile(const T* DYs, const T* __restrict__ wblob, int hbase, int lane) {
+template <typename T, typename C, typename WS, int UNROLL = 64>
+SR_DEV f32x16 dt_tile(const T* DYs, const WS& wsrc, int w3t_base, int hbase, int lane) {
   typedef BwdCfg<C> B;
   const int hh = lane >> 5;
   f32x16 acc = zero16();
-#pragma unroll
+#pragma unroll UNROLL
   for (int s = 0; s < B::KS3B; ++s) {
     const int q = 2 * s + hh;
     int off = hbase * C::F;
@@ -221,24 +256,30 @@ SR_DEV f32x16 dt_tile(const T* DYs, const T* __restrict__ wblob, int hbase, int 
       const int u = q / C::FC, c = q - u * C::FC;
       off = (hbase + (u / 3) * C::HW + (u % 3)) * C::F + c * 8;
     }
-    acc = mma16<T>(load_wfrag<T>(wblob, B::W3T_OFF + s, lane), lds_chunk<T>(DYs, off), acc);
+    acc = mma16<T>(wsrc.get(w3t_base + s, lane), lds_chunk<T>(DYs, off), acc);
   }
   return acc;
 }
 
 // ---------------------------------------------------------------------------------------------
 // backward-data: dx = dy + W1^T [ 1(h>0) * W2^T conv3x3^T(dy; W3) ],  h recomputed from x.
-// grid = (tiles, N), block 256
+// grid = (tiles, N); one wave per 32-pixel output tile (NPT_O waves).
 // ---------------------------------------------------------------------------------------------
 template <typename T, int F, int E, int L>
-__global__ __launch_bounds__(256) void wdsr_block_bwd_data_kernel(
+__global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_O)) void wdsr_block_bwd_data_kernel(
     const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, const T* __restrict__ wblob,
     const float* __restrict__ cinit, int H, int W, int tiles_x) {
   typedef BlockCfg<F, E, L> C;
   typedef BwdCfg<C> B;
   typedef typename FragOf<T>::type FragT;
   typedef typename FragOf<T>::half_type HalfT;
-  __shared__ __attribute__((aligned(16))) T smem[B::DY_ELEMS + B::XC_ELEMS];
+  constexpr int NTHREADS = 64 * C::NPT_O;
+  constexpr bool WLDS = (sizeof(T) == 2);
+  // LDS weight image: W1 (fragments 0 ..), then the contiguous blob range W3T | W2T | W1T | ID
+  constexpr int NW1 = C::NET * C::KS1, NREST = B::W2N_OFF - B::W3T_OFF;
+  constexpr int LW3T = WLDS ? NW1 : B::W3T_OFF, LW2T = LW3T + B::KS3B, LW1T = LW2T + 2 * C::NET, LID = LW1T + C::KS2;
+  constexpr int W0 = B::DY_ELEMS + B::XC_ELEMS;
+  __shared__ __attribute__((aligned(16))) T smem[W0 + (WLDS ? (NW1 + NREST) * 512 : 8)];
   T* const DYs = smem;
   T* const XC = smem + B::DY_ELEMS;
 
@@ -246,17 +287,23 @@ __global__ __launch_bounds__(256) void wdsr_block_bwd_data_kernel(
   const int n = blockIdx.y, tile = blockIdx.x;
   const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
   const size_t img = (size_t)n * H * W * F;
-  stage_dy_halo<T, C>(DYs, dy + img, H, W, ty0, tx0, tid);
-  stage_x_core<T, C>(XC, x + img, H, W, ty0, tx0, tid);
+  WSrc<T, WLDS> wsrc;
+  if constexpr (WLDS) {
+    stage_weights<T, NTHREADS>(smem + W0, wblob, NW1, tid);
+    stage_weights<T, NTHREADS>(smem + W0 + NW1 * 512, wblob + (size_t)B::W3T_OFF * 512, NREST, tid);
+    wsrc.p = smem + W0;
+  } else {
+    wsrc.p0 = wblob;
+  }
+  stage_bwd_tiles<T, C, NTHREADS>(DYs, XC, dy + img, x + img, H, W, ty0, tx0, tid);
   __syncthreads();
 
-  constexpr bool HOIST = (sizeof(T) == 2) && (F <= 24);
-  const T* const wblob0 = wblob;
-  for (int ot = wave; ot < C::NPT_O; ot += 4) {
-    wblob = weights_for_tile<HOIST>(wblob0);
+  {
+    wsrc.tile();
+    const int ot = wave;
     const int oy = (ot / (C::TW / 8)) * 4 + (r >> 3), ox = (ot % (C::TW / 8)) * 8 + (r & 7);
     const int hbase = oy * C::HW + ox, pc = oy * C::TW + ox;
-    const f32x16 dtacc = dt_tile<T, C>(DYs, wblob, hbase, lane);
+    const f32x16 dtacc = dt_tile<T, C>(DYs, wsrc, LW3T, hbase, lane);
     const FragT dtb0 = acc_to_frag<T, 0>(dtacc), dtb1 = acc_to_frag<T, 1>(dtacc);
     FragT xb[C::KS1];
 #pragma unroll
@@ -266,24 +313,20 @@ __global__ __launch_bounds__(256) void wdsr_block_bwd_data_kernel(
     for (int et = 0; et < C::NET; ++et) {
       f32x16 hacc = C::FOLD_B1 ? zero16() : load_cinit(cinit + 32 + et * 32, hh);
 #pragma unroll
-      for (int s = 0; s < C::KS1; ++s)
-        hacc = mma16<T>(load_wfrag<T>(wblob, C::W1_OFF + et * C::KS1 + s, lane), xb[s], hacc);
+      for (int s = 0; s < C::KS1; ++s) hacc = mma16<T>(wsrc.get(C::W1_OFF + et * C::KS1 + s, lane), xb[s], hacc);
       f32x16 dh = zero16();
-      dh = mma16<T>(load_wfrag<T>(wblob, B::W2T_OFF + 2 * et, lane), dtb0, dh);
-      dh = mma16<T>(load_wfrag<T>(wblob, B::W2T_OFF + 2 * et + 1, lane), dtb1, dh);
+      dh = mma16<T>(wsrc.get(LW2T + 2 * et, lane), dtb0, dh);
+      dh = mma16<T>(wsrc.get(LW2T + 2 * et + 1, lane), dtb1, dh);
 #pragma unroll
       for (int i = 0; i < 16; ++i) dh[i] = hacc[i] > 0.f ? dh[i] : 0.f;
-      if (2 * et < C::KS2)
-        dxacc = mma16<T>(load_wfrag<T>(wblob, B::W1T_OFF + 2 * et, lane), acc_to_frag<T, 0>(dh), dxacc);
-      if (2 * et + 1 < C::KS2)
-        dxacc = mma16<T>(load_wfrag<T>(wblob, B::W1T_OFF + 2 * et + 1, lane), acc_to_frag<T, 1>(dh), dxacc);
+      if (2 * et < C::KS2) dxacc = mma16<T>(wsrc.get(LW1T + 2 * et, lane), acc_to_frag<T, 0>(dh), dxacc);
+      if (2 * et + 1 < C::KS2) dxacc = mma16<T>(wsrc.get(LW1T + 2 * et + 1, lane), acc_to_frag<T, 1>(dh), dxacc);
     }
 #pragma unroll
     for (int s = 0; s < B::KSI; ++s) {
       int c = 2 * s + hh;
       if (c >= C::FC) c = 0;
-      dxacc = mma16<T>(load_wfrag<T>(wblob, B::ID_OFF + s, lane),
-                       lds_chunk<T>(DYs, (hbase + C::HW + 1) * C::F + c * 8), dxacc);
+      dxacc = mma16<T>(wsrc.get(LID + s, lane), lds_chunk<T>(DYs, (hbase + C::HW + 1) * C::F + c * 8), dxacc);
     }
     const int Y = ty0 + oy, X = tx0 + ox;
     if (Y < H && X < W) {
@@ -309,69 +352,142 @@ SR_DEV void scratch_store(T* scr, const f32x16& acc, bool valid, int r, int hh) 
   }
 }
 
+// t^T[l, px] = W2 relu(W1 x + b1) + b2 for one 32-pixel tile (rows l in regs, pixels on lanes)
+template <typename T, typename C, typename WS, int UNROLL>
+SR_DEV f32x16 t_tile(const typename FragOf<T>::type (&xb)[C::KS1], const WS& wsrc, const float* __restrict__ cinit,
+                     int lane) {
+  const int hh = lane >> 5;
+  f32x16 tacc = load_cinit(cinit, hh);
+#pragma unroll UNROLL
+  for (int e2 = 0; e2 < C::NET; ++e2) {
+    f32x16 hacc = C::FOLD_B1 ? zero16() : load_cinit(cinit + 32 + e2 * 32, hh);
+#pragma unroll
+    for (int s = 0; s < C::KS1; ++s) hacc = mma16<T>(wsrc.get(C::W1_OFF + e2 * C::KS1 + s, lane), xb[s], hacc);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) hacc[i] = fmaxf(hacc[i], 0.f);
+    if (2 * e2 < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * e2, lane), acc_to_frag<T, 0>(hacc), tacc);
+    if (2 * e2 + 1 < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * e2 + 1, lane), acc_to_frag<T, 1>(hacc), tacc);
+  }
+  return tacc;
+}
+
 // ---------------------------------------------------------------------------------------------
-// weight gradients of conv1/conv2 (+ b1, b2): pixels are the contraction index, so tiles are
-// formed "pixels in rows" by swapping MFMA operands, and the pixel-major operands (x^T, dt^T) come
-// from transposed LDS reads.  Each workgroup walks tiles t = blockIdx.x, += gridDim.x of layer
-// blockIdx.y and writes ONE partial slab (layout: packing.block_grad_tables slab A).
+// weight gradients of the block.  Pixels are the contraction index, so accumulator tiles are formed
+// "pixels in rows" by swapping MFMA operands and the pixel-major operands (x^T, dt^T, t^T, shifted dy)
+// come from transposed LDS reads.  The ~300 accumulator registers one wave would need are split over
+// the workgroup, and over two kernels so that each stays far below the 168-register / 3-waves-per-SIMD
+// budget (ROCm 7.2 hipcc must never spill here, see sr_common.h):
+//   ROLE 0 (2 NET waves): phase 1  waves 0..8: dt = conv3x3^T(dy) of one 32-pixel tile each -> LDS image
+//                         phase 2  wave (et, half): dW1^T[et], dW2[et], db1 over every second pixel tile
+//   ROLE 1 (9 waves)    : phase 1  t = W2 relu(W1 x + b1) + b2 of one pixel tile each -> LDS image
+//                         phase 2  wave u: tap u of dW3^T over all pixel tiles (b3 via t's ones channel)
+// Each workgroup walks tiles t = blockIdx.x, += gridDim.x of layer blockIdx.y and writes ONE partial
+// slab (layout: packing.block_grad_tables, slab A for ROLE 0, slab B for ROLE 1).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int F, int E, int L>
-__global__ __launch_bounds__(256, 1) void wdsr_block_wgrad12_kernel(
+template <int F, int E, int L, int ROLE> struct WgradCfg {
+  typedef BlockCfg<F, E, L> C;
+  static constexpr int NWAVES = ROLE == 0 ? 2 * C::NET : 9;          // ROLE 0 needs >= 9 (phase 1)
+};
+
+template <typename T, int F, int E, int L, int ROLE>
+__global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_block_wgrad_kernel(
     const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ wblob,
     const float* __restrict__ cinit, float* __restrict__ partial, int N, int H, int W, int tiles_x,
     int tiles_per_img, long x_ls, long dy_ls, long w_ls, long c_ls) {
   typedef BlockCfg<F, E, L> C;
   typedef BwdCfg<C> B;
+  typedef WgradCfg<F, E, L, ROLE> G;
   typedef typename FragOf<T>::type FragT;
-  constexpr int STAGE_BYTES = (B::DY_ELEMS + B::XC_ELEMS + 4 * B::SCR_ELEMS) * (int)sizeof(T);
-  constexpr int SLAB_BYTES = B::SLAB_A * 4;
-  constexpr int LDS_BYTES = STAGE_BYTES > SLAB_BYTES ? STAGE_BYTES : SLAB_BYTES;
-  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES];
+  constexpr int NTHREADS = 64 * G::NWAVES;
+  constexpr bool WLDS = (sizeof(T) == 2);
+  constexpr int IMG_ELEMS = (B::NPXC + 1) * 32;                       // dt or t image: [core px][32 ch]
+  // LDS weight image.  ROLE 0: W1 | W3T | W2N.  ROLE 1: W1 | W2 (the first fragments of the blob).
+  constexpr int NW1 = C::NET * C::KS1;
+  constexpr int LW3T = WLDS ? NW1 : B::W3T_OFF, LW2N = WLDS ? NW1 + B::KS3B : B::W2N_OFF;
+  constexpr int NWL = !WLDS ? 0 : (ROLE == 0 ? NW1 + B::KS3B + 2 * C::NET : C::W3_OFF);
+  constexpr int SLAB = ROLE == 0 ? B::SLAB_A : B::SLAB_B;
+  constexpr int STAGE_ELEMS = B::DY_ELEMS + B::XC_ELEMS + IMG_ELEMS;
+  constexpr int STAGE_BYTES = (STAGE_ELEMS + NWL * 512) * (int)sizeof(T);
+  constexpr int LDS_BYTES = STAGE_BYTES > SLAB * 4 ? STAGE_BYTES : SLAB * 4;
+  constexpr bool DB2_REGS = (sizeof(T) == 2);       // fp32 parity mode keeps db2 in LDS (register budget)
+  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES + 128];
   T* const DYs = reinterpret_cast<T*>(smem_raw);
   T* const XC = DYs + B::DY_ELEMS;
+  T* const IMG = XC + B::XC_ELEMS;
+  float* const db2lds = reinterpret_cast<float*>(smem_raw + LDS_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-  T* const scr = XC + B::XC_ELEMS + wave * B::SCR_ELEMS;
+  if (tid < 32) db2lds[tid] = 0.f;
 
   const int layer = blockIdx.y;
   x += (size_t)layer * x_ls; dy += (size_t)layer * dy_ls; wblob += (size_t)layer * w_ls; cinit += (size_t)layer * c_ls;
-  const T* const wblob0 = wblob;
+  WSrc<T, WLDS> wsrc;
+  if constexpr (WLDS) {
+    T* wl = DYs + STAGE_ELEMS;
+    if constexpr (ROLE == 0) {
+      stage_weights<T, NTHREADS>(wl, wblob, NW1, tid);
+      stage_weights<T, NTHREADS>(wl + NW1 * 512, wblob + (size_t)B::W3T_OFF * 512, B::KS3B, tid);
+      stage_weights<T, NTHREADS>(wl + (NW1 + B::KS3B) * 512, wblob + (size_t)B::W2N_OFF * 512, 2 * C::NET, tid);
+    } else {
+      stage_weights<T, NTHREADS>(wl, wblob, C::W3_OFF, tid);
+    }
+    wsrc.p = wl;
+  } else {
+    wsrc.p0 = wblob;
+  }
+  // the image's slack row is read (never written) by transposed loads: keep it finite
+  if (tid < 32) IMG[B::NPXC * 32 + tid] = (T)0.f;
 
-  f32x16 dW1T[C::NET], dW2[C::NET];
-  float db1[C::NET];
-#pragma unroll
-  for (int et = 0; et < C::NET; ++et) { dW1T[et] = zero16(); dW2[et] = zero16(); db1[et] = 0.f; }
-  f32x16 db2acc = zero16();
+  f32x16 accA = zero16(), accB = zero16();          // ROLE 0: dW1^T[et], dW2[et].  ROLE 1: accA = dW3^T[tap = wave]
+  f32x16 db2acc = zero16();                         // ROLE 0, phase-1 waves
+  float db1 = 0.f;
+  const int et = wave >> 1, half = wave & 1;
 
   for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
     const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
     const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
     const size_t img = (size_t)n * H * W * F;
     __syncthreads();
-    stage_dy_halo<T, C>(DYs, dy + img, H, W, ty0, tx0, tid);
-    stage_x_core<T, C>(XC, x + img, H, W, ty0, tx0, tid);
+    stage_bwd_tiles<T, C, NTHREADS>(DYs, XC, dy + img, x + img, H, W, ty0, tx0, tid);
     __syncthreads();
-    for (int ot = wave; ot < C::NPT_O; ot += 4) {
-      wblob = weights_for_tile<false>(wblob0);
-      const int toy = (ot / (C::TW / 8)) * 4, tox = (ot % (C::TW / 8)) * 8;
-      const int oy = toy + (r >> 3), ox = tox + (r & 7);
+
+    // ---- phase 1: dt (ROLE 0) or t (ROLE 1) of one pixel tile per wave -> LDS image (zero outside the image) ----
+    if (wave < C::NPT_O) {
+      wsrc.tile();
+      const int ot = wave;
+      const int oy = (ot / (C::TW / 8)) * 4 + (r >> 3), ox = (ot % (C::TW / 8)) * 8 + (r & 7);
       const int hbase = oy * C::HW + ox, pc = oy * C::TW + ox;
       const bool valid = (ty0 + oy < H) && (tx0 + ox < W);
-      f32x16 dtacc = dt_tile<T, C>(DYs, wblob, hbase, lane);
-      if (!valid) dtacc = zero16();
+      if constexpr (ROLE == 0) {
+        f32x16 dtacc = dt_tile<T, C, WSrc<T, WLDS>, (sizeof(T) == 2 ? 64 : 1)>(DYs, wsrc, LW3T, hbase, lane);
+        if (!valid) dtacc = zero16();
+        if constexpr (DB2_REGS) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) db2acc[i] += dtacc[i];
-      scratch_store<T>(scr, dtacc, true, r, hh);
-      FragT dtA[2], dtT[2], xA[C::KS1], xT[2];
+          for (int i = 0; i < 16; ++i) db2acc[i] += dtacc[i];
+        } else {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        dtA[s] = lds_chunk<T>(scr, r * 32 + (2 * s + hh) * 8);
-        dtT[s] = tr_frag<T>(scr, s, lane, [](int p) { return p * 32; });
-        xT[s] = tr_frag<T>(XC, s, lane, [=](int p) { return ((toy + (p >> 3)) * C::TW + tox + (p & 7)) * C::KX; });
+          for (int i = 0; i < 16; ++i) atomicAdd(db2lds + (i & 3) + 8 * (i >> 2) + 4 * hh, dtacc[i]);
+        }
+        scratch_store<T>(IMG + (pc - r) * 32, dtacc, true, r, hh);
+      } else {
+        FragT xb[C::KS1];
+#pragma unroll
+        for (int s = 0; s < C::KS1; ++s) xb[s] = lds_chunk<T>(XC, pc * C::KX + (2 * s + hh) * 8);
+        const f32x16 tacc = t_tile<T, C, WSrc<T, WLDS>, (sizeof(T) == 2 ? 64 : 1)>(xb, wsrc, cinit, lane);
+        scratch_store<T>(IMG + (pc - r) * 32, tacc, valid, r, hh);
       }
-#pragma unroll
-      for (int s = 0; s < C::KS1; ++s) xA[s] = lds_chunk<T>(XC, pc * C::KX + (2 * s + hh) * 8);
-#pragma unroll
-      for (int et = 0; et < C::NET; ++et) {
+    }
+    __syncthreads();
+
+    // ---- phase 2 ----
+    if constexpr (ROLE == 0) {
+      wsrc.tile();
+      constexpr int UNR2 = sizeof(T) == 2 ? 2 : 1;
+#pragma unroll UNR2
+      for (int ot = half; ot < C::NPT_O; ot += 2) {
+        const int toy = (ot / (C::TW / 8)) * 4, tox = (ot % (C::TW / 8)) * 8;
+        const int pc = (toy + (r >> 3)) * C::TW + tox + (r & 7);
+        auto rowx = [=](int p) { return ((toy + (p >> 3)) * C::TW + tox + (p & 7)) * C::KX; };
+        auto rowi = [=](int p) { return ((toy + (p >> 3)) * C::TW + tox + (p & 7)) * 32; };
         f32x16 h2;
         if (C::FOLD_B1) {
           h2 = zero16();
@@ -382,10 +498,11 @@ __global__ __launch_bounds__(256, 1) void wdsr_block_wgrad12_kernel(
         }
 #pragma unroll
         for (int s = 0; s < C::KS1; ++s)
-          h2 = mma16<T>(xA[s], load_wfrag<T>(wblob, C::W1_OFF + et * C::KS1 + s, lane), h2);
+          h2 = mma16<T>(lds_chunk<T>(XC, pc * C::KX + (2 * s + hh) * 8), wsrc.get(C::W1_OFF + et * C::KS1 + s, lane), h2);
         f32x16 dh2 = zero16();
 #pragma unroll
-        for (int s = 0; s < 2; ++s) dh2 = mma16<T>(dtA[s], load_wfrag<T>(wblob, B::W2N_OFF + 2 * et + s, lane), dh2);
+        for (int s = 0; s < 2; ++s)
+          dh2 = mma16<T>(lds_chunk<T>(IMG, pc * 32 + (2 * s + hh) * 8), wsrc.get(LW2N + 2 * et + s, lane), dh2);
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -393,117 +510,48 @@ __global__ __launch_bounds__(256, 1) void wdsr_block_wgrad12_kernel(
           h2[i] = fmaxf(h2[i], 0.f);
           sum += dh2[i];
         }
-        db1[et] += sum;
-        dW1T[et] = mma16<T>(xT[0], acc_to_frag<T, 0>(dh2), dW1T[et]);
-        dW1T[et] = mma16<T>(xT[1], acc_to_frag<T, 1>(dh2), dW1T[et]);
-        dW2[et] = mma16<T>(dtT[0], acc_to_frag<T, 0>(h2), dW2[et]);
-        dW2[et] = mma16<T>(dtT[1], acc_to_frag<T, 1>(h2), dW2[et]);
+        db1 += sum;
+        accA = mma16<T>(tr_frag<T>(XC, 0, lane, rowx), acc_to_frag<T, 0>(dh2), accA);
+        accA = mma16<T>(tr_frag<T>(XC, 1, lane, rowx), acc_to_frag<T, 1>(dh2), accA);
+        accB = mma16<T>(tr_frag<T>(IMG, 0, lane, rowi), acc_to_frag<T, 0>(h2), accB);
+        accB = mma16<T>(tr_frag<T>(IMG, 1, lane, rowi), acc_to_frag<T, 1>(h2), accB);
+      }
+    } else {
+      const int uy = wave / 3, ux = wave - uy * 3;    // tap u = wave
+      constexpr int UNR2 = sizeof(T) == 2 ? 3 : 1;
+#pragma unroll UNR2
+      for (int ot = 0; ot < C::NPT_O; ++ot) {
+        const int toy = (ot / (C::TW / 8)) * 4, tox = (ot % (C::TW / 8)) * 8;
+        auto rowi = [=](int p) { return ((toy + (p >> 3)) * C::TW + tox + (p & 7)) * 32; };
+        auto rowd = [=](int p) { return ((toy + (p >> 3) + uy) * C::HW + tox + (p & 7) + ux) * C::F; };
+        accA = mma16<T>(tr_frag<T>(IMG, 0, lane, rowi), tr_frag<T>(DYs, 0, lane, rowd), accA);
+        accA = mma16<T>(tr_frag<T>(IMG, 1, lane, rowi), tr_frag<T>(DYs, 1, lane, rowd), accA);
       }
     }
   }
-  // ---- reduce the 4 waves through an LDS slab, then one coalesced store per workgroup ----
+
+  // ---- reduce through an LDS slab, then one coalesced store per workgroup ----
   __syncthreads();
   float* slab = reinterpret_cast<float*>(smem_raw);
-  for (int i = tid; i < B::SLAB_A; i += 256) slab[i] = 0.f;
+  for (int i = tid; i < SLAB; i += NTHREADS) slab[i] = 0.f;
   __syncthreads();
+  if constexpr (ROLE == 0) {
+    slab_add_tile(slab, et, accA, lane);
+    slab_add_tile(slab, C::NET + et, accB, lane);
+    atomicAdd(slab + 2 * C::NET * 1024 + et * 32 + r, db1);
+    if constexpr (DB2_REGS) {
+      if (wave < C::NPT_O) {
 #pragma unroll
-  for (int et = 0; et < C::NET; ++et) {
-    slab_add_tile(slab, et, dW1T[et], lane);
-    slab_add_tile(slab, C::NET + et, dW2[et], lane);
-    atomicAdd(slab + 2 * C::NET * 1024 + et * 32 + r, db1[et]);
-  }
-#pragma unroll
-  for (int i = 0; i < 16; ++i)
-    atomicAdd(slab + 2 * C::NET * 1024 + C::NET * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh, db2acc[i]);
-  __syncthreads();
-  float* out = partial + ((size_t)layer * gridDim.x + blockIdx.x) * B::SLAB_A;
-  for (int i = tid; i < B::SLAB_A; i += 256) out[i] = slab[i];
-}
-
-// ---------------------------------------------------------------------------------------------
-// weight gradient of the 3x3 conv (+ b3 through t's ones channel): recompute t on the core pixels,
-// dW3^T[u][l, f] = sum_px t[px, l] dy[px + u - 1, f]  for the 9 read offsets u (tap = 8 - u).
-// Same walk / slab protocol as wgrad12 (slab B = 9 accumulator tiles).
-// ---------------------------------------------------------------------------------------------
-template <typename T, int F, int E, int L>
-__global__ __launch_bounds__(256, 1) void wdsr_block_wgrad3_kernel(
-    const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ wblob,
-    const float* __restrict__ cinit, float* __restrict__ partial, int N, int H, int W, int tiles_x,
-    int tiles_per_img, long x_ls, long dy_ls, long w_ls, long c_ls) {
-  typedef BlockCfg<F, E, L> C;
-  typedef BwdCfg<C> B;
-  typedef typename FragOf<T>::type FragT;
-  constexpr int STAGE_BYTES = (B::DY_ELEMS + B::XC_ELEMS + 4 * B::SCR_ELEMS) * (int)sizeof(T);
-  constexpr int SLAB_BYTES = B::SLAB_B * 4;
-  constexpr int LDS_BYTES = STAGE_BYTES > SLAB_BYTES ? STAGE_BYTES : SLAB_BYTES;
-  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES];
-  T* const DYs = reinterpret_cast<T*>(smem_raw);
-  T* const XC = DYs + B::DY_ELEMS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-  T* const scr = XC + B::XC_ELEMS + wave * B::SCR_ELEMS;
-
-  const int layer = blockIdx.y;
-  x += (size_t)layer * x_ls; dy += (size_t)layer * dy_ls; wblob += (size_t)layer * w_ls; cinit += (size_t)layer * c_ls;
-  const T* const wblob0 = wblob;
-
-  f32x16 dW3T[9];
-#pragma unroll
-  for (int u = 0; u < 9; ++u) dW3T[u] = zero16();
-
-  for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
-    const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
-    const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
-    const size_t img = (size_t)n * H * W * F;
-    __syncthreads();
-    stage_dy_halo<T, C>(DYs, dy + img, H, W, ty0, tx0, tid);
-    stage_x_core<T, C>(XC, x + img, H, W, ty0, tx0, tid);
-    __syncthreads();
-    for (int ot = wave; ot < C::NPT_O; ot += 4) {
-      wblob = weights_for_tile<false>(wblob0);
-      const int toy = (ot / (C::TW / 8)) * 4, tox = (ot % (C::TW / 8)) * 8;
-      const int oy = toy + (r >> 3), ox = tox + (r & 7);
-      const int pc = oy * C::TW + ox;
-      const bool valid = (ty0 + oy < H) && (tx0 + ox < W);
-      FragT xb[C::KS1];
-#pragma unroll
-      for (int s = 0; s < C::KS1; ++s) xb[s] = lds_chunk<T>(XC, pc * C::KX + (2 * s + hh) * 8);
-      f32x16 tacc = load_cinit(cinit, hh);
-#pragma unroll
-      for (int et = 0; et < C::NET; ++et) {
-        f32x16 hacc = C::FOLD_B1 ? zero16() : load_cinit(cinit + 32 + et * 32, hh);
-#pragma unroll
-        for (int s = 0; s < C::KS1; ++s)
-          hacc = mma16<T>(load_wfrag<T>(wblob, C::W1_OFF + et * C::KS1 + s, lane), xb[s], hacc);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) hacc[i] = fmaxf(hacc[i], 0.f);
-        if (2 * et < C::KS2)
-          tacc = mma16<T>(load_wfrag<T>(wblob, C::W2_OFF + 2 * et, lane), acc_to_frag<T, 0>(hacc), tacc);
-        if (2 * et + 1 < C::KS2)
-          tacc = mma16<T>(load_wfrag<T>(wblob, C::W2_OFF + 2 * et + 1, lane), acc_to_frag<T, 1>(hacc), tacc);
+        for (int i = 0; i < 16; ++i)
+          atomicAdd(slab + 2 * C::NET * 1024 + C::NET * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh, db2acc[i]);
       }
-      scratch_store<T>(scr, tacc, valid, r, hh);
-      FragT tT[2];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) tT[s] = tr_frag<T>(scr, s, lane, [](int p) { return p * 32; });
-#pragma unroll
-      for (int u = 0; u < 9; ++u) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          FragT d = tr_frag<T>(DYs, s, lane, [=](int p) {
-            return ((toy + (p >> 3) + u / 3) * C::HW + tox + (p & 7) + u % 3) * C::F;
-          });
-          dW3T[u] = mma16<T>(tT[s], d, dW3T[u]);
-        }
-      }
+    } else {
+      if (tid < 32) atomicAdd(slab + 2 * C::NET * 1024 + C::NET * 32 + tid, db2lds[tid]);
     }
+  } else {
+    slab_add_tile(slab, wave, accA, lane);
   }
   __syncthreads();
-  float* slab = reinterpret_cast<float*>(smem_raw);
-  for (int i = tid; i < B::SLAB_B; i += 256) slab[i] = 0.f;
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < 9; ++u) slab_add_tile(slab, u, dW3T[u], lane);
-  __syncthreads();
-  float* out = partial + ((size_t)layer * gridDim.x + blockIdx.x) * B::SLAB_B;
-  for (int i = tid; i < B::SLAB_B; i += 256) out[i] = slab[i];
+  float* out = partial + ((size_t)layer * gridDim.x + blockIdx.x) * SLAB;
+  for (int i = tid; i < SLAB; i += NTHREADS) out[i] = slab[i];
 }
