@@ -45,6 +45,11 @@ int sr_wdsr_block_fwd(const void* x, void* y, const void* wblob, const float* ci
 int sr_wdsr_block_fwd_repeat(void* x, void* y, const void* wblob, const float* cinit,
                              int N, int H, int W, int F, int dtype, int reps, sr_stream_t stream);
 
+/* Diagnostic: one forward launch (bf16) that also records, per workgroup, 6 s_memrealtime stamps (100 MHz):
+ * start, x/weights staged, after barrier, phase A done, after barrier, end -> stamps[wg][8]. */
+int sr_wdsr_block_fwd_stamps(const void* x, void* y, const void* wblob, const float* cinit, int N, int H, int W,
+                             int F, int dtype, unsigned long long* stamps, sr_stream_t stream);
+
 /* Fused residual block backward w.r.t. its input.  Replaces autograd's backward of Block.forward
  * (models/basic_wdsr_b.py:142-144): dx = dy + W1^T[1(h>0) * W2^T conv3x3^T(dy)], h recomputed from x.
  * wblob / cinit: packing.block_tables() (forward sections first). */

@@ -11,12 +11,12 @@ namespace {
 
 template <typename T, int F, int E, int L>
 int launch_block_fwd(const void* x, void* y, const void* wblob, const float* cinit, int N, int H, int W,
-                     hipStream_t st) {
+                     hipStream_t st, unsigned long long* stamps = nullptr) {
   typedef BlockCfg<F, E, L> C;
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
   dim3 grid(tiles_x * tiles_y, N), block(64 * C::NPT_H);
   hipLaunchKernelGGL((wdsr_block_fwd_kernel<T, F, E, L>), grid, block, 0, st, (const T*)x, (T*)y, (const T*)wblob,
-                     cinit, H, W, tiles_x);
+                     cinit, H, W, tiles_x, stamps);
   SR_HIP_CHECK_LAUNCH();
   return 0;
 }
@@ -51,6 +51,15 @@ int launch_block_wgrad(const void* x, const void* dy, const void* wblob, const f
 }
 
 }  // namespace
+
+extern "C" int sr_wdsr_block_fwd_stamps(const void* x, void* y, const void* wblob, const float* cinit, int N, int H,
+                                        int W, int F, int dtype, unsigned long long* stamps, sr_stream_t stream) {
+  if (F == 24 && dtype == SR_DTYPE_BF16)
+    return launch_block_fwd<__bf16, 24, 144, 20>(x, y, wblob, cinit, N, H, W, (hipStream_t)stream, stamps);
+  if (F == 32 && dtype == SR_DTYPE_BF16)
+    return launch_block_fwd<__bf16, 32, 192, 26>(x, y, wblob, cinit, N, H, W, (hipStream_t)stream, stamps);
+  return -1;
+}
 
 extern "C" int sr_wdsr_block_fwd_repeat(void* x, void* y, const void* wblob, const float* cinit, int N, int H, int W,
                                         int F, int dtype, int reps, sr_stream_t stream) {

@@ -69,11 +69,14 @@ SR_DEV void stage_x_halo(T* Xs, const T* __restrict__ xin, int H, int W, int ty0
 template <typename T, int F, int E, int L>
 __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block_fwd_kernel(
     const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ wblob,
-    const float* __restrict__ cinit, int H, int W, int tiles_x) {
+    const float* __restrict__ cinit, int H, int W, int tiles_x, unsigned long long* __restrict__ stamps) {
   typedef BlockCfg<F, E, L> C;
   typedef typename FragOf<T>::type FragT;
   typedef typename FragOf<T>::half_type HalfT;
   constexpr int NTHREADS = 64 * C::NPT_H;
+  // diagnostic phase stamps (sr_wdsr_block_fwd_stamps only; nullptr on the product path)
+#define SR_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  SR_STAMP(0);
   constexpr bool WLDS = (sizeof(T) == 2);
   constexpr int TS0 = C::NPXH_PAD * C::KX, W0 = C::NPXH_PAD * (C::KX + C::LP);
   // one LDS array (x tile, t tile, packed weights) so that every fragment address is an offset into it
@@ -94,7 +97,9 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block_fw
     wsrc.p0 = wblob;
   }
   stage_x_halo<T, C, NTHREADS>(Xs, xin, H, W, ty0, tx0, tid);
+  SR_STAMP(1);
   __syncthreads();
+  SR_STAMP(2);
 
   // ---- phase A: t = W2 relu(W1 x + b1) + b2 on every halo'd pixel (zero outside the image) ----
   {
@@ -130,7 +135,9 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block_fw
       *reinterpret_cast<HalfT*>(Ts + hp * C::LP + g * 8 + hh * 4) = v;
     }
   }
+  SR_STAMP(3);
   __syncthreads();
+  SR_STAMP(4);
 
   // ---- phase B: y = sum_taps W3_tap t(shifted) + b3 (ones channel) + x (identity chunks) ----
   if (wave < C::NPT_O) {
@@ -160,6 +167,8 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block_fw
       for (int g = 0; g < C::FC; ++g) *reinterpret_cast<HalfT*>(yo + g * 8 + hh * 4) = acc_group<T>(oacc, g);
     }
   }
+  SR_STAMP(5);
+#undef SR_STAMP
 }
 
 // =============================================================================================
