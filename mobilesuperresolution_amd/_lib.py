@@ -28,6 +28,9 @@ SIGNATURES = {
     "sr_tail_bwd_data": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_tail_wgrad": ([_P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_head_wgrad": ([_P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P], _I),
+    "sr_c3_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
+    "sr_c3_bwd_data": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
+    "sr_c3_wgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_net_forward": ([_P, _I, _P], _I),
     "sr_wdsr_net_backward": ([_P, _P], _I),
     "sr_probe_mfma_bf16": ([_P, _P, _P, _P], _I),

@@ -1,0 +1,250 @@
+// 3x3 convolution kernels of the BasicVSR propagation trunk (gfx950).  Reference ops replaced:
+// ConvResidualBlocks / ResidualBlockNoBN, models/basicvsr_arch.py:108-147 (identical copies in
+// basicvsr_arch_origin.py:98-152, mvvsr_arch.py:112-166): conv3x3(F+3 -> F) + LeakyReLU(0.1), then
+// num_block x [x + conv2(relu(conv1(x)))], plain convs with bias.
+//
+// Activations are NHWC with CI in {24, 32} input channels (the 27-channel concat is stored zero-padded
+// to 32) and 24 output channels.  The bias rides on a ones channel (index ONES, a spare slot of the
+// 32-wide LDS row) at the centre tap.  Activation: 0 none, 1 ReLU, 2 LeakyReLU(0.1).
+#pragma once
+#include "wdsr_block.h"
+
+struct C3Cfg {
+  static constexpr int CO = 24, COC = 3;                        // output channels / 8-channel chunks
+  static constexpr int TH = 12, TW = 24, HW = TW + 2, HH = TH + 2, NPXH = HW * HH, NPXH_PAD = (NPXH + 31) / 32 * 32;
+  static constexpr int NPT_O = (TH / 4) * (TW / 8), NPXC = TH * TW;
+  static constexpr int KSF = 18;                                // forward k-steps: 9 taps x 4 chunks of the 32-wide row
+  static constexpr int KSB = 14;                                // backward-data k-steps: 9 offsets x 3 chunks of dz
+  static constexpr int XH_ELEMS = (NPXH_PAD + 2) * 32;          // input tile with halo, 32 channels per pixel
+  static constexpr int XC_ELEMS = (NPXC + 1) * 32;              // core input tile
+  static constexpr int DZ_ELEMS = (NPXH_PAD + 2) * CO;          // masked output-gradient tile with halo
+};
+
+template <int ACT> SR_DEV float c3_act(float v) {
+  if (ACT == 1) return fmaxf(v, 0.f);
+  if (ACT == 2) return v > 0.f ? v : 0.1f * v;
+  return v;
+}
+template <int ACT> SR_DEV float c3_dact(float a) {               // derivative from the SAVED post-activation value
+  if (ACT == 1) return a > 0.f ? 1.f : 0.f;
+  if (ACT == 2) return a > 0.f ? 1.f : 0.1f;
+  return 1.f;
+}
+
+// x tile [rows][32]: CI channels from HBM (zero outside the image), zeros up to 32, ones channel at ONES
+template <typename T, int CI, int ONES, bool HALO, int NTHREADS>
+SR_DEV void c3_stage_x(T* Xs, const T* __restrict__ xin, int H, int W, int ty0, int tx0, int tid) {
+  typedef typename FragOf<T>::type FragT;
+  constexpr int ROWS = HALO ? C3Cfg::NPXH_PAD + 2 : C3Cfg::NPXC + 1;
+  constexpr int LIVE = HALO ? C3Cfg::NPXH : C3Cfg::NPXC;
+  constexpr int TWW = HALO ? C3Cfg::HW : C3Cfg::TW;
+  constexpr int TOTAL = ROWS * 4, ITER = (TOTAL + NTHREADS - 1) / NTHREADS;
+  FragT v[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = tid + it * NTHREADS;
+    const int p = idx >> 2, c = idx & 3;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[it][j] = (T)0.f;
+    if (idx < TOTAL && p < LIVE && c * 8 < CI) {
+      const int py = p / TWW, px = p - py * TWW;
+      const int Y = ty0 - (HALO ? 1 : 0) + py, X = tx0 - (HALO ? 1 : 0) + px;
+      if (Y >= 0 && Y < H && X >= 0 && X < W) v[it] = *reinterpret_cast<const FragT*>(xin + ((size_t)Y * W + X) * CI + c * 8);
+    }
+    if (c == ONES / 8) v[it][ONES % 8] = (T)1.f;
+  }
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = tid + it * NTHREADS;
+    if (idx < TOTAL) *reinterpret_cast<FragT*>(Xs + idx * 8) = v[it];
+  }
+}
+
+// dz tile with halo [NPXH_PAD + 2][24]: dz = dA * act'(A) (zero outside the image)
+template <typename T, int ACT, int NTHREADS>
+SR_DEV void c3_stage_dz(T* DZ, const T* __restrict__ dA, const T* __restrict__ A, int H, int W, int ty0, int tx0, int tid) {
+  typedef typename FragOf<T>::type FragT;
+  constexpr int TOTAL = (C3Cfg::NPXH_PAD + 2) * C3Cfg::COC, ITER = (TOTAL + NTHREADS - 1) / NTHREADS;
+  FragT g[ITER], a[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = tid + it * NTHREADS;
+    const int hp = idx / C3Cfg::COC, c = idx - hp * C3Cfg::COC;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { g[it][j] = (T)0.f; a[it][j] = (T)1.f; }
+    if (idx < TOTAL && hp < C3Cfg::NPXH) {
+      const int hy = hp / C3Cfg::HW, hx = hp - hy * C3Cfg::HW;
+      const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
+      if (Y >= 0 && Y < H && X >= 0 && X < W) {
+        const size_t o = ((size_t)Y * W + X) * C3Cfg::CO + c * 8;
+        g[it] = *reinterpret_cast<const FragT*>(dA + o);
+        if (ACT != 0) a[it] = *reinterpret_cast<const FragT*>(A + o);
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = tid + it * NTHREADS;
+    if (idx < TOTAL) {
+      FragT z;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = (T)((float)g[it][j] * c3_dact<ACT>((float)a[it][j]));
+      *reinterpret_cast<FragT*>(DZ + idx * 8) = z;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: y = act(conv3x3(x) + b) [+ res].  grid = (tiles, N); one wave per 32-pixel output tile.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int CI, int ONES, int ACT, bool ADD>
+__global__ __launch_bounds__((64 * C3Cfg::NPT_O)) void c3_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                                     T* __restrict__ y, const T* __restrict__ wblob,
+                                                                     int H, int W, int tiles_x) {
+  typedef C3Cfg C;
+  typedef typename FragOf<T>::half_type HalfT;
+  constexpr int NTHREADS = 64 * C::NPT_O;
+  constexpr bool WLDS = (sizeof(T) == 2);
+  __shared__ __attribute__((aligned(16))) T smem[C::XH_ELEMS + (WLDS ? C::KSF * 512 : 8)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+  WSrc<T, WLDS> wsrc;
+  if constexpr (WLDS) {
+    stage_weights<T, NTHREADS>(smem + C::XH_ELEMS, wblob, C::KSF, tid);
+    wsrc.p = smem + C::XH_ELEMS;
+  } else {
+    wsrc.p0 = wblob;
+  }
+  c3_stage_x<T, CI, ONES, true, NTHREADS>(smem, x + (size_t)n * H * W * CI, H, W, ty0, tx0, tid);
+  __syncthreads();
+  wsrc.tile();
+  const int ot = wave;
+  const int oy = (ot / (C::TW / 8)) * 4 + (r >> 3), ox = (ot % (C::TW / 8)) * 8 + (r & 7);
+  const int hbase = oy * C::HW + ox;
+  f32x16 acc = zero16();
+#pragma unroll
+  for (int s = 0; s < C::KSF; ++s) {
+    const int q = 2 * s + hh, tap = q >> 2, c = q & 3;
+    acc = mma16<T>(wsrc.get(s, lane), lds_chunk<T>(smem, (hbase + (tap / 3) * C::HW + (tap % 3)) * 32 + c * 8), acc);
+  }
+  const int Y = ty0 + oy, X = tx0 + ox;
+  if (Y < H && X < W) {
+    const size_t o = (((size_t)n * H + Y) * W + X) * C::CO;
+#pragma unroll
+    for (int g = 0; g < C::COC; ++g) {
+      HalfT v;
+      HalfT rv;
+      if (ADD) rv = *reinterpret_cast<const HalfT*>(res + o + g * 8 + hh * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float f = c3_act<ACT>(acc[4 * g + j]);
+        if (ADD) f += (float)rv[j];
+        v[j] = (T)f;
+      }
+      *reinterpret_cast<HalfT*>(y + o + g * 8 + hh * 4) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward-data: dx = conv3x3^T(dA * act'(A)) [+ add], CI output channels (rows of the tile)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int CI, int ACT, bool ADD>
+__global__ __launch_bounds__((64 * C3Cfg::NPT_O)) void c3_bwd_data_kernel(const T* __restrict__ dA, const T* __restrict__ A,
+                                                                          const T* __restrict__ add, T* __restrict__ dx,
+                                                                          const T* __restrict__ wblob, int H, int W,
+                                                                          int tiles_x) {
+  typedef C3Cfg C;
+  typedef typename FragOf<T>::half_type HalfT;
+  constexpr int NTHREADS = 64 * C::NPT_O;
+  constexpr bool WLDS = (sizeof(T) == 2);
+  __shared__ __attribute__((aligned(16))) T smem[C::DZ_ELEMS + (WLDS ? C::KSB * 512 : 8)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+  const size_t img = (size_t)n * H * W * C::CO;
+  const T* wb = wblob + (size_t)C::KSF * 512;                   // backward section follows the forward one
+  WSrc<T, WLDS> wsrc;
+  if constexpr (WLDS) {
+    stage_weights<T, NTHREADS>(smem + C::DZ_ELEMS, wb, C::KSB, tid);
+    wsrc.p = smem + C::DZ_ELEMS;
+  } else {
+    wsrc.p0 = wb;
+  }
+  c3_stage_dz<T, ACT, NTHREADS>(smem, dA + img, A + img, H, W, ty0, tx0, tid);
+  __syncthreads();
+  wsrc.tile();
+  const int ot = wave;
+  const int oy = (ot / (C::TW / 8)) * 4 + (r >> 3), ox = (ot % (C::TW / 8)) * 8 + (r & 7);
+  const int hbase = oy * C::HW + ox;
+  f32x16 acc = zero16();
+#pragma unroll
+  for (int s = 0; s < C::KSB; ++s) {
+    const int q = 2 * s + hh;
+    int off = hbase * C::CO;
+    if (q < 27) {
+      const int u = q / 3, c = q - u * 3;
+      off = (hbase + (u / 3) * C::HW + (u % 3)) * C::CO + c * 8;
+    }
+    acc = mma16<T>(wsrc.get(s, lane), lds_chunk<T>(smem, off), acc);
+  }
+  const int Y = ty0 + oy, X = tx0 + ox;
+  if (Y < H && X < W) {
+    const size_t px = ((size_t)n * H + Y) * W + X;
+#pragma unroll
+    for (int g = 0; g < CI / 8; ++g) {
+      HalfT v = acc_group<T>(acc, g);
+      if (ADD) {
+        const HalfT a = *reinterpret_cast<const HalfT*>(add + px * C::CO + g * 8 + hh * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (T)(acc[4 * g + j] + (float)a[j]);
+      }
+      *reinterpret_cast<HalfT*>(dx + px * CI + g * 8 + hh * 4) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient: slab = 9 tiles [u][ci rows, co cols], dW[co, ci, tap] = tile[8 - tap]; the ones
+// channel row of the centre tile is db.  Wave u owns tile u and walks all pixel tiles of each tile.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int CI, int ONES, int ACT>
+__global__ __launch_bounds__((64 * 9)) void c3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dA,
+                                                            const T* __restrict__ A, float* __restrict__ partial, int N,
+                                                            int H, int W, int tiles_x, int tiles_per_img) {
+  typedef C3Cfg C;
+  constexpr int NTHREADS = 576;
+  constexpr int STAGE_BYTES = (C::XC_ELEMS + C::DZ_ELEMS) * (int)sizeof(T);
+  constexpr int LDS_BYTES = STAGE_BYTES > 9 * 4096 ? STAGE_BYTES : 9 * 4096;
+  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES];
+  T* const XC = reinterpret_cast<T*>(smem_raw);
+  T* const DZ = XC + C::XC_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int uy = wave / 3, ux = wave - uy * 3;
+  f32x16 acc = zero16();
+  for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
+    const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
+    const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+    __syncthreads();
+    c3_stage_x<T, CI, ONES, false, NTHREADS>(XC, x + (size_t)n * H * W * CI, H, W, ty0, tx0, tid);
+    c3_stage_dz<T, ACT, NTHREADS>(DZ, dA + (size_t)n * H * W * C::CO, A + (size_t)n * H * W * C::CO, H, W, ty0, tx0, tid);
+    __syncthreads();
+    constexpr int UNR = sizeof(T) == 2 ? 3 : 1;
+#pragma unroll UNR
+    for (int ot = 0; ot < C::NPT_O; ++ot) {
+      const int toy = (ot / (C::TW / 8)) * 4, tox = (ot % (C::TW / 8)) * 8;
+      auto rowx = [=](int p) { return ((toy + (p >> 3)) * C::TW + tox + (p & 7)) * 32; };
+      auto rowd = [=](int p) { return ((toy + (p >> 3) + uy) * C::HW + tox + (p & 7) + ux) * C::CO; };
+      acc = mma16<T>(tr_frag<T>(XC, 0, lane, rowx), tr_frag<T>(DZ, 0, lane, rowd), acc);
+      acc = mma16<T>(tr_frag<T>(XC, 1, lane, rowx), tr_frag<T>(DZ, 1, lane, rowd), acc);
+    }
+  }
+  __syncthreads();
+  float* slab = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) slab[(wave * 16 + i) * 64 + lane] = acc[i];
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.x * 9 * 1024;
+  for (int i = tid; i < 9 * 1024; i += NTHREADS) out[i] = slab[i];
+}

@@ -4,6 +4,7 @@
 #include "wdsr_block.h"
 #include "wdsr_ends.h"
 #include "wdsr_prep.h"
+#include "conv3x3.h"
 
 extern "C" int sr_abi_version(void) { return 1; }
 
@@ -202,6 +203,83 @@ extern "C" int sr_head_wgrad(const void* dy0, const float* x, float mean, float*
 }
 
 // ------------------------------------------------------------------------------------------
+// BasicVSR trunk convolutions
+// ------------------------------------------------------------------------------------------
+namespace {
+struct C3Grid { int tx, tpi; dim3 grid; };
+inline C3Grid c3_grid(int N, int H, int W) {
+  C3Grid g;
+  g.tx = (W + C3Cfg::TW - 1) / C3Cfg::TW;
+  g.tpi = g.tx * ((H + C3Cfg::TH - 1) / C3Cfg::TH);
+  g.grid = dim3(g.tpi, N);
+  return g;
+}
+template <typename T>
+int c3_fwd_t(const void* x, const void* res, void* y, const void* w, int N, int H, int W, int CI, int act, hipStream_t st) {
+  const C3Grid g = c3_grid(N, H, W);
+  const dim3 blk(64 * C3Cfg::NPT_O);
+#define L(CI_, ONES_, ACT_, ADD_) hipLaunchKernelGGL((c3_fwd_kernel<T, CI_, ONES_, ACT_, ADD_>), g.grid, blk, 0, st, (const T*)x, (const T*)res, (T*)y, (const T*)w, H, W, g.tx)
+  if (CI == 32 && act == 2 && !res) L(32, 27, 2, false);
+  else if (CI == 24 && act == 1 && !res) L(24, 24, 1, false);
+  else if (CI == 24 && act == 0 && res) L(24, 24, 0, true);
+  else if (CI == 24 && act == 0 && !res) L(24, 24, 0, false);
+  else return -1;
+#undef L
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+template <typename T>
+int c3_bwd_t(const void* dA, const void* A, const void* add, void* dx, const void* w, int N, int H, int W, int CI, int act,
+             hipStream_t st) {
+  const C3Grid g = c3_grid(N, H, W);
+  const dim3 blk(64 * C3Cfg::NPT_O);
+#define L(CI_, ACT_, ADD_) hipLaunchKernelGGL((c3_bwd_data_kernel<T, CI_, ACT_, ADD_>), g.grid, blk, 0, st, (const T*)dA, (const T*)A, (const T*)add, (T*)dx, (const T*)w, H, W, g.tx)
+  if (CI == 32 && act == 2 && !add) L(32, 2, false);
+  else if (CI == 24 && act == 1 && add) L(24, 1, true);
+  else if (CI == 24 && act == 1 && !add) L(24, 1, false);
+  else if (CI == 24 && act == 0 && !add) L(24, 0, false);
+  else return -1;
+#undef L
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+template <typename T>
+int c3_wgrad_t(const void* x, const void* dA, const void* A, float* partial, int wgs, int N, int H, int W, int CI, int act,
+               hipStream_t st) {
+  const C3Grid g = c3_grid(N, H, W);
+#define L(CI_, ONES_, ACT_) hipLaunchKernelGGL((c3_wgrad_kernel<T, CI_, ONES_, ACT_>), dim3(wgs), dim3(576), 0, st, (const T*)x, (const T*)dA, (const T*)A, partial, N, H, W, g.tx, g.tpi)
+  if (CI == 32 && act == 2) L(32, 27, 2);
+  else if (CI == 24 && act == 1) L(24, 24, 1);
+  else if (CI == 24 && act == 0) L(24, 24, 0);
+  else return -1;
+#undef L
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+}  // namespace
+
+extern "C" int sr_c3_fwd(const void* x, const void* res, void* y, const void* wblob, int N, int H, int W, int CI,
+                         int act, int dtype, sr_stream_t stream) {
+  if (!x || !y || !wblob || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
+  return dtype == SR_DTYPE_BF16 ? c3_fwd_t<__bf16>(x, res, y, wblob, N, H, W, CI, act, (hipStream_t)stream)
+                                : c3_fwd_t<float>(x, res, y, wblob, N, H, W, CI, act, (hipStream_t)stream);
+}
+extern "C" int sr_c3_bwd_data(const void* dA, const void* A, const void* add, void* dx, const void* wblob, int N,
+                              int H, int W, int CI, int act, int dtype, sr_stream_t stream) {
+  if (!dA || !dx || !wblob || (act != 0 && !A) || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
+  if (!A) A = dA;
+  return dtype == SR_DTYPE_BF16 ? c3_bwd_t<__bf16>(dA, A, add, dx, wblob, N, H, W, CI, act, (hipStream_t)stream)
+                                : c3_bwd_t<float>(dA, A, add, dx, wblob, N, H, W, CI, act, (hipStream_t)stream);
+}
+extern "C" int sr_c3_wgrad(const void* x, const void* dA, const void* A, float* partial, int wgs, int N, int H,
+                           int W, int CI, int act, int dtype, sr_stream_t stream) {
+  if (!x || !dA || !partial || (act != 0 && !A) || wgs <= 0 || N <= 0 || H <= 0 || W <= 0) return -2;
+  if (!A) A = dA;
+  return dtype == SR_DTYPE_BF16 ? c3_wgrad_t<__bf16>(x, dA, A, partial, wgs, N, H, W, CI, act, (hipStream_t)stream)
+                                : c3_wgrad_t<float>(x, dA, A, partial, wgs, N, H, W, CI, act, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
 // whole network
 // ------------------------------------------------------------------------------------------
 namespace {
@@ -272,13 +350,13 @@ extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) 
     return rc;
   // slabs -> d(effective weights) -> d(flat parameters)
   float* d_body = n->dsrc + n->src_body_off;
-  hipLaunchKernelGGL(unpack_sum_kernel, dim3(std::min((n->n_ga + 255) / 256, 32), n->NB), dim3(256), 0, st, n->part_a,
+  hipLaunchKernelGGL(unpack_sum_kernel, dim3(std::min((n->n_ga + 63) / 64, 64), n->NB), dim3(256), 0, st, n->part_a,
                      n->wgs_body, (long)n->slab_a, n->ga_sidx, n->ga_dst, d_body, n->n_ga, n->src_body_stride);
-  hipLaunchKernelGGL(unpack_sum_kernel, dim3(std::min((n->n_gb + 255) / 256, 32), n->NB), dim3(256), 0, st, n->part_b,
+  hipLaunchKernelGGL(unpack_sum_kernel, dim3(std::min((n->n_gb + 63) / 64, 64), n->NB), dim3(256), 0, st, n->part_b,
                      n->wgs_body, (long)n->slab_b, n->gb_sidx, n->gb_dst, d_body, n->n_gb, n->src_body_stride);
-  hipLaunchKernelGGL(unpack_sum_kernel, dim3((n->n_gt + 255) / 256, 1), dim3(256), 0, st, n->part_tail, n->wgs_tail,
+  hipLaunchKernelGGL(unpack_sum_kernel, dim3((n->n_gt + 63) / 64, 1), dim3(256), 0, st, n->part_tail, n->wgs_tail,
                      (long)n->slab_tail, n->gt_sidx, n->gt_dst, n->dsrc + n->src_tail_off, n->n_gt, 0L);
-  hipLaunchKernelGGL(unpack_sum_kernel, dim3((n->n_gh + 255) / 256, 1), dim3(256), 0, st, n->part_head, n->wgs_head,
+  hipLaunchKernelGGL(unpack_sum_kernel, dim3((n->n_gh + 63) / 64, 1), dim3(256), 0, st, n->part_head, n->wgs_head,
                      (long)n->slab_head, n->gh_sidx, n->gh_dst, n->dsrc + n->src_head_off, n->n_gh, 0L);
   const int cb = (n->n_chan + 3) / 4, bb = (n->n_bias + 255) / 256;
   hipLaunchKernelGGL(wn_bwd_kernel, dim3(cb + bb), dim3(256), 0, st, n->flat, n->dsrc, n->gflat,

@@ -49,17 +49,26 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
 }
 
 // dsrc[rep * dst_stride + dst[i]] = sum_w partial[(rep * wgs + w) * slab + sidx[i]]
+// block = 256 threads = 64 elements x 4 slab groups (a quarter of the workgroup slabs each), LDS-reduced.
 __global__ __launch_bounds__(256) void unpack_sum_kernel(const float* __restrict__ partial, int wgs, long slab,
                                                          const int* __restrict__ sidx, const int* __restrict__ dst,
                                                          float* __restrict__ dsrc, int n, long dst_stride) {
-  const int rep = blockIdx.y;
+  __shared__ float red[4][64];
+  const int rep = blockIdx.y, e = threadIdx.x & 63, q = threadIdx.x >> 6;
   const float* p = partial + (size_t)rep * wgs * slab;
   float* d = dsrc + (size_t)rep * dst_stride;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const int s = sidx[i];
+  for (int base = blockIdx.x * 64; base < n; base += gridDim.x * 64) {
+    const int i = base + e;
     float acc = 0.f;
-    for (int w = 0; w < wgs; ++w) acc += p[(size_t)w * slab + s];
-    d[dst[i]] = acc;
+    if (i < n) {
+      const int s = sidx[i];
+#pragma unroll 4
+      for (int w = q; w < wgs; w += 4) acc += p[(size_t)w * slab + s];
+    }
+    red[q][e] = acc;
+    __syncthreads();
+    if (q == 0 && i < n) d[dst[i]] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+    __syncthreads();
   }
 }
 

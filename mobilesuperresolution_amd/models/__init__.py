@@ -6,8 +6,9 @@ from __future__ import annotations
 import argparse
 
 from .basic_wdsr_b import BASIC_MODEL
+from .basicvsr_arch import ConvResidualBlocks, ResidualBlockNoBN
 
-__all__ = ["BASIC_MODEL", "get_model", "update_argparser"]
+__all__ = ["BASIC_MODEL", "ConvResidualBlocks", "ResidualBlockNoBN", "get_model", "update_argparser"]
 
 _REGISTRY = {"BASIC_MODEL": BASIC_MODEL}
 

@@ -396,3 +396,36 @@ def ends_grad_tables(F: int, R: int):
     bh = _acc_pos(np.full(F, 1), np.arange(F), np.full(F, 4 * 1 + 3))
     head = np.concatenate([wh.reshape(-1), bh])
     return dict(tail=tail, tail_size=(9 * NT + 5 * NT) * 1024, head=head, head_size=3 * 1024, geom=g)
+
+
+# =====================================================================================
+# BasicVSR trunk 3x3 convs (models/basicvsr_arch.py:108-147): CI_real in {24, 27} -> 24, plain bias
+# canonical source: w (24, CI_real, 3, 3) | b (24) | 0 | 1
+# =====================================================================================
+@lru_cache(maxsize=None)
+def c3_tables(ci_real: int):
+    CO = 24
+    n_w = CO * ci_real * 9
+    o = {"w": 0, "b": n_w, "zero": n_w + CO, "one": n_w + CO + 1, "size": n_w + CO + 2}
+    # forward: rows co, chunks q = 2s+hh < 36: tap = q // 4, c = q % 4, ci = 8c + j (ones channel = ci_real)
+    s, r, hh, j = _grid(18)
+    q = 2 * s + hh
+    tap, c = q // 4, q % 4
+    ci = 8 * c + j
+    rc = np.minimum(r, CO - 1)
+    fw = np.full(s.shape, o["zero"], dtype=np.int64)
+    fw = _sel((r < CO) & (ci < ci_real), o["w"] + (rc * ci_real + np.minimum(ci, ci_real - 1)) * 9 + tap, fw)
+    fw = _sel((r < CO) & (ci == ci_real) & (tap == 4), o["b"] + rc, fw)
+    # backward-data: rows ci, chunks q < 27: u = q // 3, c = q % 3, co = 8c + j, weight tap 8 - u
+    s, r, hh, j = _grid(14)
+    q = 2 * s + hh
+    u, c = q // 3, q % 3
+    co = 8 * c + j
+    bw = _sel((q < 27) & (r < ci_real),
+              o["w"] + (co * ci_real + np.minimum(r, ci_real - 1)) * 9 + (8 - np.minimum(u, 8)), o["zero"])
+    w = np.concatenate([fw.reshape(-1), bw.reshape(-1)])
+    # gradient gather: dW[co, ci, tap] = tile[8 - tap](row ci, col co); db[co] = tile[4](row ci_real, col co)
+    co_, ci_, tap_ = np.meshgrid(np.arange(CO), np.arange(ci_real), np.arange(9), indexing="ij")
+    gw = _acc_pos(8 - tap_, ci_, co_)
+    gb = _acc_pos(np.full(CO, 4), np.full(CO, ci_real), np.arange(CO))
+    return dict(w=w, grad=np.concatenate([gw.reshape(-1), gb]), off=o)
