@@ -31,6 +31,10 @@ SIGNATURES = {
     "sr_c3_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_c3_bwd_data": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_c3_wgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    "sr_nas_dw_fwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
+    "sr_nas_pw_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
+    "sr_nas_pw_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
+    "sr_nas_dw_bwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_net_forward": ([_P, _I, _P], _I),
     "sr_wdsr_net_backward": ([_P, _P], _I),
     "sr_probe_mfma_bf16": ([_P, _P, _P, _P], _I),

@@ -1,0 +1,464 @@
+// NAS supernet residual block (gfx950).  Reference ops replaced: Split_Block.forward_body with
+// Conv_sep(seperate=True) branches and the BinaryConv2d masks, models/wdsr_b.py:375-496, models/ops.py:7-43,
+// inside MyAggregationLayer.forward (:517-546) and NAS_MODEL.forward's per-block global mask (:116):
+//
+//   x  = mg * yin                      (global channel mask, BinaryConv2d, least_channel 8)
+//   x1 = ms * x                        (block split mask, least_channel 0)
+//   S  = sum_k p_k relu(pw_k(relu(dw_k(x1) + bd_k)) + bp_k),  k in {3,5,7},  p = softmax(alpha)
+//   y  = x + beta2 * ms * S            (beta2 in {0,1}: the hard skip/keep gate; beta1 + beta2 = 1)
+//
+// Four kernels: depthwise forward (VALU; the three stencils share one LDS halo-3 tile, weights arrive
+// through wave-uniform scalar loads), pointwise forward (MFMA, fused mix + masks), and their backward
+// halves.  Intermediates v_k = relu(dw_k(x1)) and gz_k = d(loss)/d(dw_k output) live in HBM.
+// Float parameter table `dwp` (channels padded to 32): W3 | W5 | W7 | BD[3] | M1 = mg*ms | MG | MS.
+#pragma once
+#include "wdsr_block.h"
+
+template <int F_> struct NasCfg {
+  static constexpr int F = F_, FC = F / 8;
+  static constexpr int TH = 12, TW = 24, NPXC = TH * TW, NPT_O = (TH / 4) * (TW / 8);
+  static constexpr int PW = TW + 6, PH = TH + 6, NP3 = PW * PH;          // tile with a 3-pixel halo
+  static constexpr int P3_ELEMS = (NP3 + 2) * F;
+  static constexpr int W3 = 0, W5 = 9 * 32, W7 = W5 + 25 * 32, BD = W7 + 49 * 32, M1 = BD + 3 * 32, MG = M1 + 32,
+                       MS = MG + 32, DWP = MS + 32;
+  static constexpr int NGRP = (NPXC + 63) / 64;                          // 64-pixel groups of the core tile
+  static constexpr int NITEM = NGRP * FC;                                // (pixel group, 8-channel chunk) items
+  static constexpr int VT_ELEMS = (NPXC + 1) * 32;                       // core tile, 32 channels per pixel
+  // pw backward slab per branch k: tile [co rows, ci cols] | db[32] | r[32]; then one scalar
+  static constexpr int PWB_K = 1024 + 64, PWB_SLAB = 3 * PWB_K + 4;
+  // dw backward slab: dW[83 taps][32] | db[3][32] | sA[32] | sB[32]
+  static constexpr int DWB_SLAB = (83 + 3 + 2) * 32;
+};
+
+SR_DEV int nas_woff(int k) { return k == 0 ? 0 : (k == 1 ? 9 * 32 : 9 * 32 + 25 * 32); }
+
+// halo-3 tile [NP3 + 2][F] of `src` scaled per channel by scale[c] (nullptr: 1), zero outside the image
+template <typename T, typename C, int NTHREADS>
+SR_DEV void nas_stage_halo3(T* dst, const T* __restrict__ src, const float* __restrict__ scale, int H, int W, int ty0,
+                            int tx0, int tid) {
+  typedef typename FragOf<T>::type FragT;
+  constexpr int TOTAL = (C::NP3 + 2) * C::FC;
+  for (int idx = tid; idx < TOTAL; idx += NTHREADS) {
+    const int hp = idx / C::FC, c = idx - hp * C::FC;
+    FragT v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (T)0.f;
+    if (hp < C::NP3) {
+      const int hy = hp / C::PW, hx = hp - hy * C::PW;
+      const int Y = ty0 - 3 + hy, X = tx0 - 3 + hx;
+      if (Y >= 0 && Y < H && X >= 0 && X < W) {
+        v = *reinterpret_cast<const FragT*>(src + ((size_t)Y * W + X) * C::F + c * 8);
+        if (scale) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (T)((float)v[j] * scale[c * 8 + j]);
+        }
+      }
+    }
+    *reinterpret_cast<FragT*>(dst + hp * C::F + c * 8) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// depthwise forward: V_k = relu(dw_k(m1 * yin) + bd_k), k = 3, 5, 7.  grid = (tiles, N), 8 waves.
+// A wave item = 64 pixels x one 8-channel chunk, so the stencil weights are wave-uniform (s_load).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int F>
+__global__ __launch_bounds__(512) void nas_dw_fwd_kernel(const T* __restrict__ yin, T* __restrict__ V,
+                                                         const float* __restrict__ dwp, int H, int W, int tiles_x,
+                                                         long vstride) {
+  typedef NasCfg<F> C;
+  typedef typename FragOf<T>::type FragT;
+  __shared__ __attribute__((aligned(16))) T X1[C::P3_ELEMS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+  const size_t img = (size_t)n * H * W * F;
+  nas_stage_halo3<T, C, 512>(X1, yin + img, dwp + C::M1, H, W, ty0, tx0, tid);
+  __syncthreads();
+  for (int item0 = wave; item0 < C::NITEM; item0 += 8) {
+    const int item = __builtin_amdgcn_readfirstlane(item0);
+    const int g = item / C::FC, c = item - g * C::FC;
+    const int px = g * 64 + lane;
+    const bool valid = px < C::NPXC;
+    const int oy = valid ? px / C::TW : 0, ox = valid ? px % C::TW : 0;
+    const float* w = dwp + c * 8;                                   // wave-uniform
+    float z3[8], z5[8], z7[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { z3[j] = w[C::BD + j]; z5[j] = w[C::BD + 32 + j]; z7[j] = w[C::BD + 64 + j]; }
+#pragma unroll 1
+    for (int ty = 0; ty < 7; ++ty) {
+#pragma unroll 1
+      for (int tx = 0; tx < 7; ++tx) {
+        const FragT v = *reinterpret_cast<const FragT*>(X1 + ((oy + ty) * C::PW + ox + tx) * F + c * 8);
+        const bool in5 = ty >= 1 && ty <= 5 && tx >= 1 && tx <= 5, in3 = ty >= 2 && ty <= 4 && tx >= 2 && tx <= 4;
+        const float* w7 = w + C::W7 + (ty * 7 + tx) * 32;
+        const float* w5 = w + C::W5 + (in5 ? ((ty - 1) * 5 + tx - 1) * 32 : 0);
+        const float* w3 = w + C::W3 + (in3 ? ((ty - 2) * 3 + tx - 2) * 32 : 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = (float)v[j];
+          z7[j] += w7[j] * f;
+          z5[j] += in5 ? w5[j] * f : 0.f;
+          z3[j] += in3 ? w3[j] * f : 0.f;
+        }
+      }
+    }
+    const int Y = ty0 + oy, X = tx0 + ox;
+    if (valid && Y < H && X < W) {
+      const size_t o = img + ((size_t)Y * W + X) * F + c * 8;
+      FragT a, b, d;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a[j] = (T)fmaxf(z3[j], 0.f); b[j] = (T)fmaxf(z5[j], 0.f); d[j] = (T)fmaxf(z7[j], 0.f); }
+      *reinterpret_cast<FragT*>(V + o) = a;
+      *reinterpret_cast<FragT*>(V + vstride + o) = b;
+      *reinterpret_cast<FragT*>(V + 2 * vstride + o) = d;
+    }
+  }
+}
+
+// core tile of one V_k as [NPXC + 1][32] (channels >= F zero)
+template <typename T, typename C, int NTHREADS>
+SR_DEV void nas_stage_vt(T* VT, const T* __restrict__ v, int H, int W, int ty0, int tx0, int tid) {
+  typedef typename FragOf<T>::type FragT;
+  for (int idx = tid; idx < (C::NPXC + 1) * 4; idx += NTHREADS) {
+    const int pc = idx >> 2, c = idx & 3;
+    FragT f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (T)0.f;
+    if (pc < C::NPXC && c < C::FC) {
+      const int Y = ty0 + pc / C::TW, X = tx0 + pc % C::TW;
+      if (Y < H && X < W) f = *reinterpret_cast<const FragT*>(v + ((size_t)Y * W + X) * C::F + c * 8);
+    }
+    *reinterpret_cast<FragT*>(VT + idx * 8) = f;
+  }
+}
+
+// 16 accumulator-layout values (rows = channels 8g + 4hh + j) of pixel `px` from an NHWC tensor; rows >= F are 0
+template <typename T, int F> SR_DEV void nas_load_rows(float (&out)[16], const T* __restrict__ p, int hh) {
+  typedef typename FragOf<T>::half_type HalfT;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g < F / 8) {
+      const HalfT v = *reinterpret_cast<const HalfT*>(p + g * 8 + hh * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[4 * g + j] = (float)v[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[4 * g + j] = 0.f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pointwise forward + mix: y = mg*yin + beta2 * ms * sum_k p_k relu(pw_k V_k + bp_k).
+// frags: 6 forward fragments (k, k-step); tabs: bp[3][32] | ms_row[32] | mg_row[32] in C-init layout;
+// scal: p0, p1, p2, beta2.  grid = (tiles, N), one wave per 32-pixel tile.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int F>
+__global__ __launch_bounds__(576) void nas_pw_fwd_kernel(const T* __restrict__ yin, const T* __restrict__ V,
+                                                         T* __restrict__ y, const T* __restrict__ frags,
+                                                         const float* __restrict__ tabs, const float* __restrict__ scal,
+                                                         int H, int W, int tiles_x, long vstride) {
+  typedef NasCfg<F> C;
+  typedef typename FragOf<T>::half_type HalfT;
+  __shared__ __attribute__((aligned(16))) T VT[3 * C::VT_ELEMS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+  const size_t img = (size_t)n * H * W * F;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) nas_stage_vt<T, C, 576>(VT + k * C::VT_ELEMS, V + k * vstride + img, H, W, ty0, tx0, tid);
+  __syncthreads();
+  const T* fr = weights_for_tile<false>(frags);
+  const int ot = wave;
+  const int oy = (ot / (C::TW / 8)) * 4 + (r >> 3), ox = (ot % (C::TW / 8)) * 8 + (r & 7);
+  const int pc = oy * C::TW + ox;
+  float S[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) S[i] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    f32x16 acc = load_cinit(tabs + k * 32, hh);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      acc = mma16<T>(load_wfrag<T>(fr, 2 * k + s, lane), lds_chunk<T>(VT + k * C::VT_ELEMS, pc * 32 + (2 * s + hh) * 8), acc);
+    const float p = scal[k];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S[i] += p * fmaxf(acc[i], 0.f);
+  }
+  const int Y = ty0 + oy, X = tx0 + ox;
+  if (Y < H && X < W) {
+    const size_t o = img + ((size_t)Y * W + X) * F;
+    const f32x16 ms = load_cinit(tabs + 96, hh), mg = load_cinit(tabs + 128, hh);
+    const float b2 = scal[3];
+    float xin[16];
+    nas_load_rows<T, F>(xin, yin + o, hh);
+#pragma unroll
+    for (int g = 0; g < C::FC; ++g) {
+      HalfT v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (T)(mg[4 * g + j] * xin[4 * g + j] + b2 * ms[4 * g + j] * S[4 * g + j]);
+      *reinterpret_cast<HalfT*>(y + o + g * 8 + hh * 4) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pointwise backward: recompute u_k; gu_k = p_k beta2 ms gy 1(u_k>0); GZ_k = (Wpw_k^T gu_k) 1(V_k>0);
+// per-branch slabs: dWpw_k [co rows, ci cols], dbp_k = sum gu_k, r_k[c] = sum gy[c] relu(u_k)[c]; scalar
+// sxy = sum gy * mg * yin.  Wave (k, grp) owns branch k and pixel tiles grp, grp+2, ... (6 waves).
+// frags: 6 forward + 6 backward (rows ci, k = co chained).  grid = (wgs), persistent over tiles.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int F>
+__global__ __launch_bounds__(384) void nas_pw_bwd_kernel(const T* __restrict__ yin, const T* __restrict__ V,
+                                                         const T* __restrict__ gy, T* __restrict__ GZ,
+                                                         const T* __restrict__ frags, const float* __restrict__ tabs,
+                                                         const float* __restrict__ scal, float* __restrict__ partial,
+                                                         int N, int H, int W, int tiles_x, int tiles_per_img, long vstride) {
+  typedef NasCfg<F> C;
+  typedef typename FragOf<T>::half_type HalfT;
+  constexpr int SCR = 33 * 32;
+  constexpr int STAGE_BYTES = (3 * C::VT_ELEMS + 6 * SCR) * (int)sizeof(T);
+  constexpr int LDS_BYTES = STAGE_BYTES > C::PWB_SLAB * 4 ? STAGE_BYTES : C::PWB_SLAB * 4;
+  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES];
+  T* const VT = reinterpret_cast<T*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  T* const scr = VT + 3 * C::VT_ELEMS + wave * SCR;
+  const int k = wave >> 1, grp = wave & 1;          // 6 waves: (branch, pixel-tile parity)
+  const T* const VTk = VT + k * C::VT_ELEMS;
+  f32x16 dW = zero16();
+  float db[16], rk[16], sxy = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { db[i] = 0.f; rk[i] = 0.f; }
+  const float coef = scal[k] * scal[3];                        // p_k * beta2
+
+  for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
+    const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
+    const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+    const size_t img = (size_t)n * H * W * F;
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) nas_stage_vt<T, C, 384>(VT + kk * C::VT_ELEMS, V + kk * vstride + img, H, W, ty0, tx0, tid);
+    __syncthreads();
+    const T* fr = weights_for_tile<false>(frags);
+#pragma unroll 1
+    for (int ot = grp; ot < C::NPT_O; ot += 2) {
+      const int toy = (ot / (C::TW / 8)) * 4, tox = (ot % (C::TW / 8)) * 8;
+      const int oy = toy + (r >> 3), ox = tox + (r & 7);
+      const int pc = oy * C::TW + ox;
+      const int Y = ty0 + oy, X = tx0 + ox;
+      const bool valid = Y < H && X < W;
+      const size_t o = img + ((size_t)(valid ? Y : 0) * W + (valid ? X : 0)) * F;
+      f32x16 acc = load_cinit(tabs + k * 32, hh);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) acc = mma16<T>(load_wfrag<T>(fr, 2 * k + s, lane), lds_chunk<T>(VTk, pc * 32 + (2 * s + hh) * 8), acc);
+      float g[16];
+      nas_load_rows<T, F>(g, gy + o, hh);
+      if (!valid) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) g[i] = 0.f;
+      }
+      if (k == 0) {
+        float xin[16];
+        nas_load_rows<T, F>(xin, yin + o, hh);
+        const f32x16 mg = load_cinit(tabs + 128, hh);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sxy += g[i] * mg[i] * xin[i];
+      }
+      f32x16 gu;
+      {
+        const f32x16 ms = load_cinit(tabs + 96, hh);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          rk[i] += g[i] * fmaxf(acc[i], 0.f);
+          gu[i] = acc[i] > 0.f ? coef * ms[i] * g[i] : 0.f;
+          db[i] += gu[i];
+        }
+      }
+      // d(loss)/d(dw_k output) = (Wpw_k^T gu) * 1(v_k > 0), rows ci
+      f32x16 gv = zero16();
+      gv = mma16<T>(load_wfrag<T>(fr, 6 + 2 * k, lane), acc_to_frag<T, 0>(gu), gv);
+      gv = mma16<T>(load_wfrag<T>(fr, 6 + 2 * k + 1, lane), acc_to_frag<T, 1>(gu), gv);
+      if (valid) {
+#pragma unroll
+        for (int gq = 0; gq < C::FC; ++gq) {
+          const HalfT vv = *reinterpret_cast<const HalfT*>(VTk + pc * 32 + gq * 8 + hh * 4);
+          HalfT z;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) z[j] = (float)vv[j] > 0.f ? (T)gv[4 * gq + j] : (T)0.f;
+          *reinterpret_cast<HalfT*>(GZ + k * vstride + o + gq * 8 + hh * 4) = z;
+        }
+      }
+      // dWpw_k[co, ci] += sum_px gu[px, co] v_k[px, ci]
+      scratch_store<T>(scr, gu, true, r, hh);
+      auto rows = [](int p) { return p * 32; };
+      auto rowv = [=](int p) { return ((toy + (p >> 3)) * C::TW + tox + (p & 7)) * 32; };
+      dW = mma16<T>(tr_frag<T>(scr, 0, lane, rows), tr_frag<T>(VTk, 0, lane, rowv), dW);
+      dW = mma16<T>(tr_frag<T>(scr, 1, lane, rows), tr_frag<T>(VTk, 1, lane, rowv), dW);
+    }
+  }
+  __syncthreads();
+  float* slab = reinterpret_cast<float*>(smem_raw);
+  for (int i = tid; i < C::PWB_SLAB; i += 384) slab[i] = 0.f;
+  __syncthreads();
+  float* sk = slab + k * C::PWB_K;
+  slab_add_tile(sk, 0, dW, lane);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+    atomicAdd(sk + 1024 + row, db[i]);
+    atomicAdd(sk + 1024 + 32 + row, rk[i]);
+  }
+  if (k == 0) atomicAdd(slab + 3 * C::PWB_K, sxy);
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.x * C::PWB_SLAB;
+  for (int i = tid; i < C::PWB_SLAB; i += 384) out[i] = slab[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// depthwise backward: g_br = sum_k dw_k^T(GZ_k); g_x = gy + ms g_br; g_yin = mg g_x;
+// slab: dWdw[83 taps][32] | dbd[3][32] | sA[c] = sum g_br mg yin | sB[c] = sum g_x yin.
+// (a) weight gradients: lanes = channels, the taps of each stencil are dealt over the 8 waves;
+// (b) data gradient: (pixel group, chunk) items as in the forward.  grid = (wgs), persistent over tiles.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int F>
+__global__ __launch_bounds__(512) void nas_dw_bwd_kernel(const T* __restrict__ yin, const T* __restrict__ GZ,
+                                                         const T* __restrict__ gy, T* __restrict__ gyin,
+                                                         const float* __restrict__ dwp, float* __restrict__ partial,
+                                                         int N, int H, int W, int tiles_x, int tiles_per_img, long vstride) {
+  typedef NasCfg<F> C;
+  typedef typename FragOf<T>::type FragT;
+  constexpr int MAXIT = (C::NITEM + 7) / 8;
+  constexpr int STAGE_BYTES = 2 * C::P3_ELEMS * (int)sizeof(T);
+  constexpr int LDS_BYTES = STAGE_BYTES > C::DWB_SLAB * 4 ? STAGE_BYTES : C::DWB_SLAB * 4;
+  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES];
+  T* const X1 = reinterpret_cast<T*>(smem_raw);
+  T* const GT = X1 + C::P3_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ch = lane & 31, half = lane >> 5;
+  // weight-gradient accumulators of this wave's taps: 2 slots for the 3x3, 4 for the 5x5, 7 for the 7x7
+  float accw[13], accb[3], sA[MAXIT][8], sB[MAXIT][8];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) accw[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) accb[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXIT; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sA[i][j] = 0.f; sB[i][j] = 0.f; }
+
+  for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
+    const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
+    const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+    const size_t img = (size_t)n * H * W * F;
+    float gbr[MAXIT][8];
+#pragma unroll
+    for (int i = 0; i < MAXIT; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gbr[i][j] = 0.f;
+    __syncthreads();
+    nas_stage_halo3<T, C, 512>(X1, yin + img, dwp + C::M1, H, W, ty0, tx0, tid);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int ks = 3 + 2 * k, off = 3 - ks / 2, wbase = nas_woff(k);
+      const int sbase = k == 0 ? 0 : (k == 1 ? 2 : 6), nslot = k == 0 ? 2 : (k == 1 ? 4 : 7);
+      __syncthreads();
+      nas_stage_halo3<T, C, 512>(GT, GZ + k * vstride + img, nullptr, H, W, ty0, tx0, tid);
+      __syncthreads();
+      // (b) data gradient through the flipped stencil
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) {
+        const int item = __builtin_amdgcn_readfirstlane(wave + 8 * it);
+        if (item < C::NITEM) {
+          const int g = item / C::FC, c = item - g * C::FC;
+          const int px = g * 64 + lane;
+          const bool valid = px < C::NPXC;
+          const int oy = valid ? px / C::TW : 0, ox = valid ? px % C::TW : 0;
+          const float* w = dwp + wbase + c * 8;
+          for (int ty = 0; ty < ks; ++ty) {
+            for (int tx = 0; tx < ks; ++tx) {
+              const FragT v = *reinterpret_cast<const FragT*>(GT + ((oy + off + ty) * C::PW + ox + off + tx) * F + c * 8);
+              const float* wt = w + ((ks - 1 - ty) * ks + (ks - 1 - tx)) * 32;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) gbr[it][j] += wt[j] * (float)v[j];
+            }
+          }
+        }
+      }
+      // (a) weight gradient: lane = channel, taps tp = wave, wave + 8, ...; two lane halves split the pixels
+      if (ch < F) {
+        const int ntap = ks * ks;
+        for (int p = half; p < C::NPXC; p += 2) {
+          const int oy = p / C::TW, ox = p - oy * C::TW;
+          const float gz = (float)GT[((oy + 3) * C::PW + ox + 3) * F + ch];
+          if (wave == 0) accb[k] += gz;
+#pragma unroll
+          for (int i = 0; i < 7; ++i) {
+            const int tp = wave + 8 * i;
+            if (i < nslot && tp < ntap) {
+              const int ty = tp / ks, tx = tp - ty * ks;
+              accw[sbase + i] += gz * (float)X1[((oy + off + ty) * C::PW + ox + off + tx) * F + ch];
+            }
+          }
+        }
+      }
+    }
+    // epilogue of the data gradient
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int item = __builtin_amdgcn_readfirstlane(wave + 8 * it);
+      if (item < C::NITEM) {
+        const int g = item / C::FC, c = item - g * C::FC;
+        const int px = g * 64 + lane;
+        const int oy = px / C::TW, ox = px % C::TW;
+        const int Y = ty0 + oy, X = tx0 + ox;
+        if (px < C::NPXC && Y < H && X < W) {
+          const size_t o = img + ((size_t)Y * W + X) * F + c * 8;
+          const FragT yv = *reinterpret_cast<const FragT*>(yin + o), gv = *reinterpret_cast<const FragT*>(gy + o);
+          FragT outv;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float mgc = dwp[C::MG + c * 8 + j], msc = dwp[C::MS + c * 8 + j];
+            const float gx = (float)gv[j] + msc * gbr[it][j];
+            outv[j] = (T)(mgc * gx);
+            sA[it][j] += gbr[it][j] * mgc * (float)yv[j];
+            sB[it][j] += gx * (float)yv[j];
+          }
+          *reinterpret_cast<FragT*>(gyin + o) = outv;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* slab = reinterpret_cast<float*>(smem_raw);
+  for (int i = tid; i < C::DWB_SLAB; i += 512) slab[i] = 0.f;
+  __syncthreads();
+  if (ch < F) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int ks = 3 + 2 * k, ntap = ks * ks, tbase = nas_woff(k) / 32;
+      const int sbase = k == 0 ? 0 : (k == 1 ? 2 : 6), nslot = k == 0 ? 2 : (k == 1 ? 4 : 7);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int tp = wave + 8 * i;
+        if (i < nslot && tp < ntap) atomicAdd(slab + (tbase + tp) * 32 + ch, accw[sbase + i]);
+      }
+      if (wave == 0) atomicAdd(slab + (83 + k) * 32 + ch, accb[k]);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int item = wave + 8 * it;
+    if (item < C::NITEM) {
+      const int c = item % C::FC;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float a = wave_sum(sA[it][j]), b = wave_sum(sB[it][j]);
+        if (lane == 0) { atomicAdd(slab + 86 * 32 + c * 8 + j, a); atomicAdd(slab + 87 * 32 + c * 8 + j, b); }
+      }
+    }
+  }
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.x * C::DWB_SLAB;
+  for (int i = tid; i < C::DWB_SLAB; i += 512) out[i] = slab[i];
+}

@@ -5,6 +5,7 @@
 #include "wdsr_ends.h"
 #include "wdsr_prep.h"
 #include "conv3x3.h"
+#include "nas_block.h"
 
 extern "C" int sr_abi_version(void) { return 1; }
 
@@ -277,6 +278,64 @@ extern "C" int sr_c3_wgrad(const void* x, const void* dA, const void* A, float* 
   if (!A) A = dA;
   return dtype == SR_DTYPE_BF16 ? c3_wgrad_t<__bf16>(x, dA, A, partial, wgs, N, H, W, CI, act, (hipStream_t)stream)
                                 : c3_wgrad_t<float>(x, dA, A, partial, wgs, N, H, W, CI, act, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// NAS supernet block
+// ------------------------------------------------------------------------------------------
+#define SR_NAS_DISPATCH(CALL)                                                                   \
+  if (F == 24 && dtype == SR_DTYPE_BF16) { CALL(__bf16, 24) } else if (F == 24 && dtype == SR_DTYPE_F32) { CALL(float, 24) } \
+  else if (F == 32 && dtype == SR_DTYPE_BF16) { CALL(__bf16, 32) } else if (F == 32 && dtype == SR_DTYPE_F32) { CALL(float, 32) } \
+  else return -1;
+
+extern "C" int sr_nas_dw_fwd(const void* yin, void* V, const float* dwp, int N, int H, int W, int F, int dtype,
+                             sr_stream_t stream) {
+  if (!yin || !V || !dwp || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const long vs = (long)N * H * W * F;
+#define CALL(T, F_) { typedef NasCfg<F_> C; const int tx = (W + C::TW - 1) / C::TW; dim3 g(tx * ((H + C::TH - 1) / C::TH), N); \
+    hipLaunchKernelGGL((nas_dw_fwd_kernel<T, F_>), g, dim3(512), 0, st, (const T*)yin, (T*)V, dwp, H, W, tx, vs); }
+  SR_NAS_DISPATCH(CALL)
+#undef CALL
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int sr_nas_pw_fwd(const void* yin, const void* V, void* y, const void* frags, const float* tabs,
+                             const float* scal, int N, int H, int W, int F, int dtype, sr_stream_t stream) {
+  if (!yin || !V || !y || !frags || !tabs || !scal || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const long vs = (long)N * H * W * F;
+#define CALL(T, F_) { typedef NasCfg<F_> C; const int tx = (W + C::TW - 1) / C::TW; dim3 g(tx * ((H + C::TH - 1) / C::TH), N); \
+    hipLaunchKernelGGL((nas_pw_fwd_kernel<T, F_>), g, dim3(576), 0, st, (const T*)yin, (const T*)V, (T*)y, (const T*)frags, tabs, scal, H, W, tx, vs); }
+  SR_NAS_DISPATCH(CALL)
+#undef CALL
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int sr_nas_pw_bwd(const void* yin, const void* V, const void* gy, void* GZ, const void* frags,
+                             const float* tabs, const float* scal, float* partial, int wgs, int N, int H, int W, int F,
+                             int dtype, sr_stream_t stream) {
+  if (!yin || !V || !gy || !GZ || !frags || !tabs || !scal || !partial || wgs <= 0 || N <= 0 || H <= 0 || W <= 0) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const long vs = (long)N * H * W * F;
+#define CALL(T, F_) { typedef NasCfg<F_> C; const int tx = (W + C::TW - 1) / C::TW, tpi = tx * ((H + C::TH - 1) / C::TH); \
+    hipLaunchKernelGGL((nas_pw_bwd_kernel<T, F_>), dim3(wgs), dim3(384), 0, st, (const T*)yin, (const T*)V, (const T*)gy, (T*)GZ, (const T*)frags, tabs, scal, partial, N, H, W, tx, tpi, vs); }
+  SR_NAS_DISPATCH(CALL)
+#undef CALL
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int sr_nas_dw_bwd(const void* yin, const void* GZ, const void* gy, void* gyin, const float* dwp,
+                             float* partial, int wgs, int N, int H, int W, int F, int dtype, sr_stream_t stream) {
+  if (!yin || !GZ || !gy || !gyin || !dwp || !partial || wgs <= 0 || N <= 0 || H <= 0 || W <= 0) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const long vs = (long)N * H * W * F;
+#define CALL(T, F_) { typedef NasCfg<F_> C; const int tx = (W + C::TW - 1) / C::TW, tpi = tx * ((H + C::TH - 1) / C::TH); \
+    hipLaunchKernelGGL((nas_dw_bwd_kernel<T, F_>), dim3(wgs), dim3(512), 0, st, (const T*)yin, (const T*)GZ, (const T*)gy, (T*)gyin, dwp, partial, N, H, W, tx, tpi, vs); }
+  SR_NAS_DISPATCH(CALL)
+#undef CALL
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -136,6 +136,17 @@ def pack_ends(src_head: torch.Tensor, src_tail: torch.Tensor, F: int, R: int, dt
     return bh, bt
 
 
+def pack_head(src_head: torch.Tensor, F: int, dtype: torch.dtype):
+    tb = ends_tables(F, 4, src_head.device)
+    return src_head.detach().float().index_select(0, tb["head"]).to(dtype).contiguous()
+
+
+def pack_tail(src_tail: torch.Tensor, F: int, R: int, dtype: torch.dtype):
+    tb = ends_tables(F, R, src_tail.device)
+    assert src_tail.numel() == tb["tail_size"]
+    return src_tail.detach().float().index_select(0, tb["tail"]).to(dtype).contiguous()
+
+
 def head_fwd(x: torch.Tensor, y: torch.Tensor, blob: torch.Tensor, mean: float):
     n, _, h, w = x.shape
     _launch("sr_head_fwd", L.lib().sr_head_fwd, L.ptr(x), L.ptr(y), L.ptr(blob), mean, n, h, w, y.shape[-1],

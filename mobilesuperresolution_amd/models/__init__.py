@@ -7,10 +7,12 @@ import argparse
 
 from .basic_wdsr_b import BASIC_MODEL
 from .basicvsr_arch import ConvResidualBlocks, ResidualBlockNoBN
+from .wdsr_b import NAS_MODEL, ModelOutput
 
-__all__ = ["BASIC_MODEL", "ConvResidualBlocks", "ResidualBlockNoBN", "get_model", "update_argparser"]
+__all__ = ["BASIC_MODEL", "NAS_MODEL", "ModelOutput", "ConvResidualBlocks", "ResidualBlockNoBN", "get_model",
+           "update_argparser"]
 
-_REGISTRY = {"BASIC_MODEL": BASIC_MODEL}
+_REGISTRY = {"BASIC_MODEL": BASIC_MODEL, "NAS_MODEL": NAS_MODEL}
 
 
 def update_argparser(parser: argparse.ArgumentParser):

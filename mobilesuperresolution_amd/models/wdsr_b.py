@@ -1,0 +1,430 @@
+"""NAS supernet (NAS_MODEL, MyAggregationLayer / Split_Block, Conv_sep, ConditionFunction) on the MI355X hot path.
+
+Mirrors reference models/wdsr_b.py: same class names, constructor fields (`params.width_search`,
+`params.pretrained`, ...), `forward(x) -> (sr, speed_accu)`, search-control methods (`get_current_blocks`,
+`get_block_status`, `get_width_from_block_idx`, `length_grad`, `mask_grad`, `kernel_grad`, ...) and
+state_dict keys (`body.{i}.{alpha,beta,alpha1,beta1,alpha2,beta2,split.weight,body.{3,5,7}.0.body.{0,2}.*}`,
+`mask.weight`, `head.*`, `tail.*`, `skip.*`, `speed_estimator.estimator.fc*`).
+
+Per block, everything between the block's input and output -- global mask, split mask, the three
+depthwise-separable branches, softmax mixing, the hard skip/keep gate -- runs in csrc/nas_block.h
+(4 kernels forward+backward).  The scalar glue (softmax over 3 alphas, the straight-through masks and
+gate, the closed-form latency head of speed_models/speed_estimator.py:57-76) stays in PyTorch.
+Head and tail reuse the kernels of BASIC_MODEL.  No CPU / ATen fallback.
+"""
+from __future__ import annotations
+
+import math
+import os
+from collections import namedtuple
+from functools import lru_cache
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.nn.init as init
+
+from .. import _lib as L
+from .. import hotpath as HP
+from .. import packing as P
+from .ops import BinaryConv2d, rounding
+
+ModelOutput = namedtuple("ModelOutput", "sr speed_accu speed_curr")
+
+__all__ = ["NAS_MODEL", "ModelOutput", "MyAggregationLayer", "Split_Block", "Conv_sep", "ConditionFunction"]
+
+_DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
+
+
+def _hot_dtype(params) -> torch.dtype:
+    name = getattr(params, "hot_dtype", None) or os.environ.get("SR_HOT_DTYPE", "fp32")
+    return name if isinstance(name, torch.dtype) else _DTYPES[str(name).lower()]
+
+
+class _WNConv(nn.Module):
+    """parameters of torch.nn.utils.weight_norm(nn.Conv2d(...)): bias, weight_g, weight_v.
+    g_init None = weight_norm's own initialisation (g = ||v||, i.e. w = v)."""
+
+    def __init__(self, cin, cout, k, groups=1, g_init=None, zero_bias=False):
+        super().__init__()
+        conv = nn.Conv2d(cin, cout, k, groups=groups)
+        v = conv.weight.detach().clone()
+        self.bias = nn.Parameter(torch.zeros(cout) if zero_bias else conv.bias.detach().clone())
+        g = v.flatten(1).norm(dim=1).view(-1, 1, 1, 1) if g_init is None else torch.full((cout, 1, 1, 1), float(g_init))
+        self.weight_g = nn.Parameter(g)
+        self.weight_v = nn.Parameter(v)
+
+    def weight(self):
+        v = self.weight_v
+        return v * (self.weight_g / v.flatten(1).norm(dim=1).view(-1, 1, 1, 1))
+
+
+class Conv_sep(nn.Module):
+    """reference wdsr_b.py:375-402 with seperate=True: wn depthwise kxk -> ReLU -> wn 1x1 (keys body.0 / body.2)"""
+
+    def __init__(self, input_dim, output_dim, kernal_size, weight_norm=None, seperate=True):
+        super().__init__()
+        if not seperate or input_dim != output_dim:
+            raise NotImplementedError("hot path supports Conv_sep(seperate=True, input_dim == output_dim)")
+        self.seperate, self.kernel_size = seperate, kernal_size
+        self.body = nn.ModuleList([_WNConv(input_dim, input_dim, kernal_size, groups=input_dim), nn.Identity(),
+                                   _WNConv(input_dim, output_dim, 1)])
+
+
+class ConditionFunction(torch.autograd.Function):
+    """hard gate (reference wdsr_b.py:594-616): (1,0) if alpha1 >= alpha2 else (0,1); straight-through to alpha."""
+
+    @staticmethod
+    def forward(ctx, alpha1, alpha2, beta1, beta2):
+        with torch.no_grad():
+            if alpha1 >= alpha2:
+                beta1.data = beta1.new_ones(1)
+                beta2.data = beta2.new_zeros(1)
+            else:
+                beta1.data = beta1.new_zeros(1)
+                beta2.data = beta2.new_ones(1)
+        return beta1, beta2
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        return g1, g2, None, None
+
+
+@lru_cache(maxsize=None)
+def _nas_dev_tables(Fch: int, device_index: int):
+    t = P.nas_tables(Fch)
+    dev = torch.device("cuda", device_index)
+    out = {k: (torch.from_numpy(np.ascontiguousarray(v)).to(dev) if isinstance(v, np.ndarray) else v) for k, v in t.items()
+           if k != "g_wdw" and k != "off"}
+    out["g_wdw"] = [torch.from_numpy(a).to(dev) for a in t["g_wdw"]]
+    out["off"] = t["off"]
+    return out
+
+
+class _NasBlockFunction(torch.autograd.Function):
+    """y = mg*yin + beta2 * ms * sum_k p_k relu(pw_k(relu(dw_k(mg*ms*yin)))) on csrc/nas_block.h"""
+
+    @staticmethod
+    def forward(ctx, yin, wdw3, wdw5, wdw7, bdw, wpw, bpw, mg, ms, p, beta):
+        n, h, w, f = yin.shape
+        dev, dt = yin.device, yin.dtype
+        tb = _nas_dev_tables(f, dev.index if dev.index is not None else torch.cuda.current_device())
+        src = torch.cat([t.detach().float().reshape(-1) for t in (wdw3, wdw5, wdw7, bdw, wpw, bpw, mg, ms, mg * ms)]
+                        + [yin.new_tensor([0.0, 1.0], dtype=torch.float32)])
+        assert src.numel() == tb["off"]["size"]
+        dwp = src.index_select(0, tb["dwp"]).contiguous()
+        frags = src.index_select(0, tb["frags"]).to(dt).contiguous()
+        tabs = src.index_select(0, tb["tabs"]).contiguous()
+        scal = torch.cat([p.detach().float().reshape(-1), beta.detach().float().reshape(-1)[1:2]]).contiguous()
+        code = L.DTYPE_CODE[dt]
+        V = torch.empty((3, n, h, w, f), dtype=dt, device=dev)
+        y = torch.empty_like(yin)
+        st = L.stream_ptr
+        L.launch("sr_nas_dw_fwd", L.lib().sr_nas_dw_fwd, yin.data_ptr(), V.data_ptr(), dwp.data_ptr(), n, h, w, f, code, st())
+        L.launch("sr_nas_pw_fwd", L.lib().sr_nas_pw_fwd, yin.data_ptr(), V.data_ptr(), y.data_ptr(), frags.data_ptr(),
+                 tabs.data_ptr(), scal.data_ptr(), n, h, w, f, code, st())
+        ctx.save_for_backward(yin, V, dwp, frags, tabs, scal, mg.detach().float(), ms.detach().float(), p.detach().float(),
+                              beta.detach().float())
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        yin, V, dwp, frags, tabs, scal, mg, ms, p, beta = ctx.saved_tensors
+        n, h, w, f = yin.shape
+        dev, dt = yin.device, yin.dtype
+        tb = _nas_dev_tables(f, dev.index if dev.index is not None else torch.cuda.current_device())
+        code = L.DTYPE_CODE[dt]
+        gy = gy.contiguous()
+        wgs = 64
+        GZ = torch.empty_like(V)
+        part_pw = torch.empty((wgs, tb["pw_slab"]), dtype=torch.float32, device=dev)
+        part_dw = torch.empty((wgs, tb["dw_slab"]), dtype=torch.float32, device=dev)
+        gyin = torch.empty_like(yin)
+        st = L.stream_ptr
+        L.launch("sr_nas_pw_bwd", L.lib().sr_nas_pw_bwd, yin.data_ptr(), V.data_ptr(), gy.data_ptr(), GZ.data_ptr(),
+                 frags.data_ptr(), tabs.data_ptr(), scal.data_ptr(), part_pw.data_ptr(), wgs, n, h, w, f, code, st())
+        L.launch("sr_nas_dw_bwd", L.lib().sr_nas_dw_bwd, yin.data_ptr(), GZ.data_ptr(), gy.data_ptr(), gyin.data_ptr(),
+                 dwp.data_ptr(), part_dw.data_ptr(), wgs, n, h, w, f, code, st())
+        spw, sdw = part_pw.sum(0), part_dw.sum(0)
+        g_wpw = spw.index_select(0, tb["g_wpw"]).view(3, f, f, 1, 1)
+        g_bpw = spw.index_select(0, tb["g_bpw"]).view(3, f)
+        r = spw.index_select(0, tb["g_r"]).view(3, f)                  # r_k[c] = sum gy[c] relu(u_k)[c]
+        sxy = spw[tb["sxy"]]
+        g_wdw = [sdw.index_select(0, tb["g_wdw"][i]).view(f, 1, k, k) for i, k in enumerate((3, 5, 7))]
+        g_bdw = sdw.index_select(0, tb["g_bdw"]).view(3, f)
+        sA, sB = sdw.index_select(0, tb["g_sA"]), sdw.index_select(0, tb["g_sB"])
+        b2 = beta[1]
+        q = (r * ms.view(1, f)).sum(1)                                  # q_k = sum_c ms[c] r_k[c]
+        g_p = b2 * q
+        g_beta = torch.stack([sxy, sxy + (p * q).sum()])
+        g_ms = sA + b2 * (p.view(3, 1) * r).sum(0)
+        g_mg = sB
+        return gyin, g_wdw[0], g_wdw[1], g_wdw[2], g_bdw, g_wpw, g_bpw, g_mg, g_ms, g_p, g_beta
+
+
+class Split_Block(nn.Module):
+    """reference wdsr_b.py:405-501 (block_type 'normal', seperate_type True)"""
+
+    def __init__(self, num_residual_units, kernel_size=3, weight_norm=None, res_scale=1, width_search=False,
+                 block_type="normal", seperate_type=True):
+        super().__init__()
+        if block_type != "normal" or not seperate_type:
+            raise NotImplementedError("hot path supports Split_Block(block_type='normal', seperate_type=True)")
+        self.num_residual_units = num_residual_units
+        self.alpha = nn.Parameter(torch.ones(3))
+        init.uniform_(self.alpha, 0.5, 1.5)
+        self.beta = nn.Parameter(torch.zeros(3))
+        self.split = BinaryConv2d(num_residual_units, num_residual_units, groups=num_residual_units, least_channel=0)
+        self.kernel_list = ["3", "5", "7"]
+        self.body = nn.ModuleDict()
+        for k in self.kernel_list:
+            self.body[k] = nn.Sequential(Conv_sep(num_residual_units, num_residual_units, int(k)), nn.Identity())
+
+    def _branch_params(self):
+        wdw = [self.body[k][0].body[0].weight() for k in self.kernel_list]
+        bdw = torch.stack([self.body[k][0].body[0].bias for k in self.kernel_list])
+        wpw = torch.stack([self.body[k][0].body[2].weight() for k in self.kernel_list])
+        bpw = torch.stack([self.body[k][0].body[2].bias for k in self.kernel_list])
+        return wdw, bdw, wpw, bpw
+
+    def _run(self, yin, mg, beta):
+        """yin NHWC hot tensor; mg (F,) global-mask values (ones outside NAS_MODEL); beta (2,) gate"""
+        wdw, bdw, wpw, bpw = self._branch_params()
+        p = F.softmax(self.alpha, dim=0)                      # implicit dim 0 in the reference (:487)
+        return _NasBlockFunction.apply(yin, wdw[0], wdw[1], wdw[2], bdw, wpw, bpw, mg, self.split.effective(), p, beta)
+
+    def forward_body(self, x):
+        """NCHW fp32 in / out, as the reference's forward_body (:482-496)"""
+        if not x.is_cuda:
+            raise L.HotpathError("Split_Block (MI355X hot path) needs CUDA/HIP tensors; there is no CPU fallback")
+        dt = getattr(self, "hot_dtype", torch.float32)
+        yin = x.permute(0, 2, 3, 1).to(dt).contiguous()
+        y = self._run(yin, x.new_ones(self.num_residual_units), x.new_tensor([0.0, 1.0]))
+        return y.permute(0, 3, 1, 2).float()
+
+    def forward(self, x):
+        return self.forward_body(x)
+
+
+class MyAggregationLayer(Split_Block):
+    """reference wdsr_b.py:503-554: Split_Block + hard skip/keep gate (alpha1/alpha2, beta1/beta2)"""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.alpha1 = nn.Parameter(torch.empty(1))
+        self.beta1 = nn.Parameter(torch.zeros(1))
+        init.uniform_(self.alpha1, 0, 0.2)
+        self.alpha2 = nn.Parameter(torch.empty(1))
+        self.beta2 = nn.Parameter(torch.ones(1))
+        init.uniform_(self.alpha2, 0.8, 1)
+
+    def forward(self, y, mg, speed_curr, speed_accu):
+        """y: NHWC hot tensor BEFORE the global mask; mg: (F,) effective global mask (applied in-kernel).
+        Returns (y_out NHWC, speed_accu) with the reference's train / eval semantics (:517-546)."""
+        if self.training:
+            beta1, beta2 = ConditionFunction.apply(self.alpha1, self.alpha2, self.beta1, self.beta2)
+            self.beta1.data, self.beta2.data = beta1.detach(), beta2.detach()
+            out = self._run(y, mg, torch.cat([beta1, beta2]))
+            return out, beta2 * speed_curr + speed_accu
+        if self.alpha1 >= self.alpha2:
+            out = (y.float() * mg.view(1, 1, 1, -1)).to(y.dtype)          # skipped block: only the global mask
+        else:
+            out = self._run(y, mg, y.new_tensor([0.0, 1.0], dtype=torch.float32))
+        return out, speed_accu + self.beta2 * speed_curr
+
+
+class _SpeedMLP(nn.Module):
+    """parameter holder of speed_models/SpeedModel.py:9-39 (6-layer MLP); loaded-but-unused at this commit"""
+
+    def __init__(self, num_feat=3):
+        super().__init__()
+        self.fc1, self.fc2, self.fc3 = nn.Linear(num_feat, 32), nn.Linear(32, 64), nn.Linear(64, 128)
+        self.fc6, self.fc7, self.fc8 = nn.Linear(128, 64), nn.Linear(64, 32), nn.Linear(32, 1)
+        for p in self.parameters():
+            p.requires_grad = False
+
+
+class BlockBSpeedEstimator(nn.Module):
+    """latency head, host/PyTorch scalars (speed_models/speed_estimator.py): the closed form used at this commit"""
+
+    def __init__(self, type):
+        super().__init__()
+        self.estimator = _SpeedMLP(3)
+        self.type = type
+
+    @torch.no_grad()
+    def estimateByMyMask(self, module, block_mask):
+        """sum_k (c_split + 0.2 c_mask) k^2 alpha_k / 40, alpha RAW (speed_estimator.py:57-76); both channel counts
+        use rounding() with its default least_channel=8 (get_unmask_number, :79-83)."""
+        c_mask = rounding(block_mask.weight.detach()).sum()
+        c_split = rounding(module.split.weight.detach()).sum()
+        k2 = module.alpha.new_tensor([9.0, 25.0, 49.0])
+        return ((c_split + 0.2 * c_mask) * k2 * module.alpha.detach() / 40).sum().reshape(1)
+
+    @torch.no_grad()
+    def estimateByChannelNum(self, x):
+        return (x[1] + 0.2 * x[0]) * (x[2] * x[2]) / 40
+
+
+def get_ori_speed(num_blocks=4, num_residual_units=12):
+    """speed_models/helpers.py:5-15"""
+    return float(num_blocks * (num_residual_units + 0.2 * num_residual_units) * 49 / 40)
+
+
+class _HeadFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, f, dt, mean):
+        blob = HP.pack_head(HP.head_src(w, b), f, dt)
+        n, _, h, wd = x.shape
+        y = torch.empty((n, h, wd, f), dtype=dt, device=x.device)
+        HP.head_fwd(x, y, blob, mean)
+        ctx.save_for_backward(x)
+        ctx.mean, ctx.shape_w = mean, w.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        g = HP.head_wgrad(gy.contiguous(), x, ctx.mean)
+        nw = int(np.prod(ctx.shape_w))
+        return None, g[:nw].view(ctx.shape_w), g[nw:nw + ctx.shape_w[0]], None, None, None
+
+
+class _TailFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, x, wt, ws, btot, r, mean):
+        n, h, w, f = feat.shape
+        blob = HP.pack_tail(HP.tail_src(wt, ws, btot), f, r, feat.dtype)
+        out = torch.empty((n, 3, r * h, r * w), dtype=torch.float32, device=feat.device)
+        HP.tail_fwd(feat, x, out, blob, mean, r)
+        ctx.save_for_backward(feat, x, blob)
+        ctx.r, ctx.mean, ctx.shapes = r, mean, (wt.shape, ws.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feat, x, blob = ctx.saved_tensors
+        dout = dout.contiguous().float()
+        dfeat = torch.empty_like(feat)
+        HP.tail_bwd_data(dout, dfeat, blob, ctx.r)
+        g = HP.tail_wgrad(dout, feat, x, ctx.mean, ctx.r)
+        nt, ns = int(np.prod(ctx.shapes[0])), int(np.prod(ctx.shapes[1]))
+        co = ctx.shapes[0][0]
+        return dfeat, None, g[:nt].view(ctx.shapes[0]), g[nt:nt + ns].view(ctx.shapes[1]), g[nt + ns:nt + ns + co], None, None
+
+
+class NAS_MODEL(nn.Module):
+
+    def __init__(self, params):
+        super().__init__()
+        self.image_mean = float(params.image_mean)
+        self.scale = int(params.scale)
+        self.num_blocks = int(params.num_blocks)
+        self.num_residual_units = f = int(params.num_residual_units)
+        self.remain_blocks = params.num_blocks
+        self.width_search = bool(params.width_search)
+        self.idx_kernel = [3, 5, 7]
+        nin = int(params.num_channels)
+        if nin != 3 or f not in (24, 32) or self.scale not in (2, 3, 4):
+            raise NotImplementedError("MI355X hot path supports num_channels=3, num_residual_units in {24,32}, "
+                                      f"scale in {{2,3,4}} (got {nin}, {f}, {self.scale})")
+        if not self.width_search:
+            # the reference's forward dereferences self.mask, which exists only with width_search (wdsr_b.py:74-77,116)
+            raise NotImplementedError("NAS_MODEL(width_search=False) cannot run in the reference either "
+                                      "(forward uses self.mask); construct it with width_search=True")
+        self.hot_dtype = _hot_dtype(params)
+        nout = self.scale * self.scale * nin
+        self.head = _WNConv(nin, f, 3, g_init=1.0, zero_bias=True)
+        self.speed_estimator = BlockBSpeedEstimator("mask" if params.width_search else "channel").eval()
+        self.body = nn.ModuleList([MyAggregationLayer(num_residual_units=f, kernel_size=3,
+                                                      res_scale=1 / math.sqrt(self.num_blocks), width_search=True)
+                                   for _ in range(self.num_blocks)])
+        self.mask = BinaryConv2d(in_channels=f, out_channels=f, groups=f)
+        self.tail = _WNConv(f, nout, 3, g_init=1.0, zero_bias=True)
+        self.skip = _WNConv(nin, nout, 5, g_init=1.0, zero_bias=True)        # bare conv in NAS_MODEL: keys skip.*
+        self.shuf = nn.Sequential()
+        if getattr(params, "pretrained", False):
+            raise NotImplementedError("load_pretrained (positional copy from models/pretrained_weights) is not on the hot path; "
+                                      "load a BASIC_MODEL checkpoint explicitly")
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise L.HotpathError("NAS_MODEL (MI355X hot path) needs CUDA/HIP tensors; there is no CPU fallback")
+        x = x.contiguous().float()
+        f, dt = self.num_residual_units, self.hot_dtype
+        y = _HeadFunction.apply(x, self.head.weight(), self.head.bias, f, dt, self.image_mean)
+        speed_accu = x.new_zeros(1)
+        mg = self.mask.effective()
+        for module in self.body:
+            speed_curr = self.speed_estimator.estimateByMyMask(module, self.mask)
+            y, speed_accu = module(y, mg, speed_curr, speed_accu)
+        y = (y.float() * mg.view(1, 1, 1, -1)).to(dt)                         # y = self.mask(y) before the tail (:118-119)
+        btot = self.tail.bias + self.skip.bias + self.image_mean
+        out = _TailFunction.apply(y, x, self.tail.weight(), self.skip.weight(), btot, self.scale, self.image_mean)
+        return out, speed_accu
+
+    # ---- search-control surface used by search.py:83-87,292,331-337,374-380 ----
+    @torch.no_grad()
+    def get_current_blocks(self):
+        return int(sum(1 for m in self.body if m.alpha1 < m.alpha2))
+
+    @torch.no_grad()
+    def get_block_status(self):
+        out = []
+        for idx, m in enumerate(self.body):
+            a1, a2 = F.softmax(torch.stack([m.alpha1, m.alpha2], dim=0), dim=0)
+            if a1 < a2:
+                out.append(idx)
+        return out
+
+    @torch.no_grad()
+    def get_width_from_block_idx(self, remain_block_idx):
+        all_width = []
+        for idx, m in enumerate(self.body):
+            if idx in remain_block_idx:
+                width = [int(rounding(self.mask.weight).sum()),
+                         int((rounding(self.mask.weight) * rounding(m.split.weight)).sum())]
+                _, max_index = torch.max(m.alpha, 0)
+                width.append(self.idx_kernel[max_index])
+                all_width.append(width)
+        return all_width
+
+    @torch.no_grad()
+    def get_alpha_grad(self):
+        for m in self.body:
+            return m.alpha1.grad, m.alpha2.grad
+
+    @torch.no_grad()
+    def get_alpha(self):
+        for m in self.body:
+            return m.alpha1, m.alpha2
+
+    @torch.no_grad()
+    def length_grad(self, flag=False):
+        for m in self.body:
+            for p in (m.alpha1, m.alpha2, m.beta1, m.beta2):
+                p.requires_grad = flag
+
+    @torch.no_grad()
+    def mask_grad(self, flag=False):
+        for m in self.body:
+            m.split.weight.requires_grad = flag
+        self.mask.weight.requires_grad = flag
+
+    @torch.no_grad()
+    def kernel_grad(self, flag=False):
+        for m in self.body:
+            _, max_index = torch.max(m.alpha, 0)
+            temp = torch.zeros(3, device=m.alpha.device)
+            temp[max_index] = 1
+            m.alpha.data = temp
+            m.alpha.requires_grad = flag
+
+    @torch.no_grad()
+    def get_mask_grad(self):
+        return self.mask.weight.grad
+
+    @torch.no_grad()
+    def get_mask_weight(self):
+        return self.mask.weight.data

@@ -429,3 +429,56 @@ def c3_tables(ci_real: int):
     gw = _acc_pos(8 - tap_, ci_, co_)
     gb = _acc_pos(np.full(CO, 4), np.full(CO, ci_real), np.arange(CO))
     return dict(w=w, grad=np.concatenate([gw.reshape(-1), gb]), off=o)
+
+
+# =====================================================================================
+# NAS supernet block (models/wdsr_b.py:375-496): canonical source per block
+#   wdw3 (F,9) | wdw5 (F,25) | wdw7 (F,49) | bdw (3,F) | wpw (3,F,F) | bpw (3,F) | mg (F) | ms (F) | m1 (F) | 0 | 1
+# =====================================================================================
+@lru_cache(maxsize=None)
+def nas_tables(F: int):
+    o, off = {}, 0
+    for name, n in (("wdw3", F * 9), ("wdw5", F * 25), ("wdw7", F * 49), ("bdw", 3 * F), ("wpw", 3 * F * F),
+                    ("bpw", 3 * F), ("mg", F), ("ms", F), ("m1", F), ("zero", 1), ("one", 1)):
+        o[name] = off
+        off += n
+    o["size"] = off
+    Z = o["zero"]
+    ch = np.arange(32)
+    chc = np.minimum(ch, F - 1)
+    dwp = []
+    for key, kk in (("wdw3", 9), ("wdw5", 25), ("wdw7", 49)):
+        tap = np.arange(kk).reshape(-1, 1)
+        dwp.append(np.where(ch < F, o[key] + chc * kk + tap, Z).reshape(-1))       # [tap][32]
+    for k in range(3):
+        dwp.append(np.where(ch < F, o["bdw"] + k * F + chc, Z))
+    for key in ("m1", "mg", "ms"):
+        dwp.append(np.where(ch < F, o[key] + chc, Z))
+    dwp = np.concatenate(dwp)
+    assert dwp.size == (83 + 3 + 3) * 32
+    # pointwise fragments: forward (rows co, k = ci natural), backward (rows ci, k = co chained)
+    fw, bw = [], []
+    for k in range(3):
+        s, r, hh, j = _grid(2)
+        ci = k_natural(s, hh, j)
+        fw.append(_sel((r < F) & (ci < F), o["wpw"] + (k * F + np.minimum(r, F - 1)) * F + np.minimum(ci, F - 1), Z))
+        co = k_chained(s, hh, j)
+        bw.append(_sel((r < F) & (co < F), o["wpw"] + (k * F + np.minimum(co, F - 1)) * F + np.minimum(r, F - 1), Z))
+    frags = np.concatenate([a.reshape(-1) for a in fw + bw])
+    tabs = []
+    for k in range(3):
+        rows = np.where(ch < F, o["bpw"] + k * F + chc, Z)
+        tabs.append(cinit_index(rows, Z))
+    for key in ("ms", "mg"):
+        tabs.append(cinit_index(np.where(ch < F, o[key] + chc, Z), Z))
+    tabs = np.concatenate(tabs)
+    # gradient gathers
+    co_, ci_ = np.meshgrid(np.arange(F), np.arange(F), indexing="ij")
+    g_wpw = np.stack([k * 1088 + _acc_pos(0, co_, ci_) for k in range(3)]).reshape(-1)
+    g_bpw = np.stack([k * 1088 + 1024 + np.arange(F) for k in range(3)]).reshape(-1)
+    g_r = np.stack([k * 1088 + 1056 + np.arange(F) for k in range(3)]).reshape(-1)
+    tb = (0, 9, 34)
+    g_wdw = [np.stack([(tb[i] + np.arange(kk)) * 32 + c for c in range(F)]).reshape(-1) for i, kk in enumerate((9, 25, 49))]
+    g_bdw = np.stack([(83 + k) * 32 + np.arange(F) for k in range(3)]).reshape(-1)
+    return dict(off=o, dwp=dwp, frags=frags, tabs=tabs, g_wpw=g_wpw, g_bpw=g_bpw, g_r=g_r, g_wdw=g_wdw, g_bdw=g_bdw,
+                g_sA=86 * 32 + np.arange(F), g_sB=87 * 32 + np.arange(F), pw_slab=3 * 1088 + 4, dw_slab=88 * 32, sxy=3 * 1088)

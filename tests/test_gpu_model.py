@@ -139,4 +139,33 @@ def test_boundary_errors():
         _model(_ns(num_residual_units=48))
     with pytest.raises(NotImplementedError):
         from mobilesuperresolution_amd.models import get_model
-        get_model(_ns(model_type="NAS_MODEL"))
+        get_model(_ns(model_type="Result_Model"))
+
+
+def test_ddp_rccl_single_rank_step():
+    """DistributedDataParallel over RCCL (backend 'nccl') wraps the flat-parameter model and steps, as
+    pretrain.py:157,239 does; world_size 1 here (one GPU per box), world 2 semantics are covered on gloo."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        torch.manual_seed(0)
+        m = _model(_ns(num_blocks=2, hot_dtype="bf16")).train()
+        ref_flat = m.flat.detach().clone()
+        ddp = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], gradient_as_bucket_view=True)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        x = torch.rand(4, 3, 24, 24, device="cuda")
+        hr = torch.rand(4, 3, 96, 96, device="cuda")
+        losses = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.l1_loss(ddp(x), hr)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        assert m.flat.grad is not None and torch.isfinite(m.flat.grad).all()
+        assert not torch.equal(m.flat.detach(), ref_flat) and losses[-1] < losses[0]
+        assert len(ddp.state_dict()) == 3 * (3 * 2 + 3) and "module.skip.0.weight_v" in ddp.state_dict()
+    finally:
+        dist.destroy_process_group()

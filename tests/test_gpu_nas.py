@@ -1,0 +1,114 @@
+"""Parity of the NAS supernet pieces on the HIP path: BinaryConv2d/rounding (G5), Split_Block.forward_body
+with all gradients (G6, golden vectors from the reference), and the NAS_MODEL composition against the
+oracle's restated glue (whole-model composition: parity unpinned, see oracle.nas_model_forward)."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wdsr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def test_g5_rounding_and_effective_mask(golden_dir):
+    from mobilesuperresolution_amd.models.ops import BinaryConv2d, rounding
+    d = _load(golden_dir, "g5_binary_mask.npz")
+    for name in ("all_keep", "straddle", "fallback", "ties"):
+        w = d[f"{name}/w"]
+        for lc in (8, 0):
+            assert torch.equal(rounding(w, lc), d[f"{name}/mask_lc{lc}"])
+        m = BinaryConv2d(24, 24, groups=24, least_channel=8)
+        with torch.no_grad():
+            m.weight.copy_(w)
+        eff = m.effective()
+        assert torch.equal(eff.detach(), d[f"{name}/mask_lc8"].reshape(-1))
+        # forward value x * mask and straight-through gradient, vs the reference's conv
+        x = d[f"{name}/x"]
+        y = x * eff.view(1, -1, 1, 1)
+        assert torch.equal(y.detach(), d[f"{name}/y"])
+        y.backward(d[f"{name}/dy"])
+        torch.testing.assert_close(m.weight.grad, d[f"{name}/dw"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("f", [24, 32])
+def test_g6_split_block_fp32_matches_reference(golden_dir, f):
+    from mobilesuperresolution_amd.models.wdsr_b import Split_Block
+    d = _load(golden_dir, f"g6_split_block_f{f}.npz")
+    blk = Split_Block(num_residual_units=f, kernel_size=3)
+    sd = {k[2:]: v for k, v in d.items() if k.startswith("p/")}
+    assert set(blk.state_dict().keys()) == set(sd.keys())
+    blk.load_state_dict(sd, strict=True)
+    blk = blk.cuda()
+    x = d["x"].cuda().requires_grad_(True)
+    y = blk.forward_body(x)
+    err = (y.detach().cpu() - d["y"]).abs().max().item() / d["y"].abs().max().item()
+    print(f"\nG6 F={f} fwd rel err {err:.2e}")
+    assert err <= 1e-5
+    y.backward(d["dy"].cuda())
+    e = (x.grad.cpu() - d["dx"]).abs().max().item() / d["dx"].abs().max().item()
+    print(f"G6 F={f} dx rel err {e:.2e}")
+    assert e <= 1e-5
+    worst = 0.0
+    for k, p in blk.named_parameters():
+        if "g/" + k not in d:
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, k      # beta: unused
+            continue
+        exp = d["g/" + k]
+        ge = (p.grad.cpu() - exp).abs().max().item() / max(exp.abs().max().item(), 1e-12)
+        worst = max(worst, ge)
+        assert ge <= 2e-4, (k, ge)
+    print(f"G6 F={f} worst param-grad rel err {worst:.2e}")
+
+
+def _nas_ns(**kw):
+    ns = argparse.Namespace(model_type="NAS_MODEL", image_mean=0.5, num_channels=3, scale=4, num_blocks=3,
+                            num_residual_units=24, width_search=True, pretrained=False, hot_dtype="fp32")
+    for k, v in kw.items():
+        setattr(ns, k, v)
+    return ns
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_nas_model_matches_oracle_glue(training):
+    from mobilesuperresolution_amd.models import get_model
+    torch.manual_seed(3)
+    m = get_model(_nas_ns())
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        m.mask.weight.copy_(torch.rand(24, 1, 1, 1, generator=g) * 0.7 + 0.25)      # some global channels off
+        for i, blk in enumerate(m.body):
+            blk.split.weight.copy_(torch.rand(24, 1, 1, 1, generator=g) * 0.7 + 0.2)
+        m.body[1].alpha1.fill_(1.5)                                                 # block 1 is skipped (alpha1 >= alpha2)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    m = m.cuda().train(training)
+    x = torch.rand(2, 3, 20, 28, generator=g)
+    hr = torch.rand(2, 3, 80, 112, generator=g)
+    out, speed = m(x.cuda())
+    ref, rspeed = O.nas_model_forward(x, sd, 4, 0.5, training)
+    err = (out.detach().cpu() - ref.detach()).abs().max().item() / ref.abs().max().item()
+    print(f"\nNAS model ({'train' if training else 'eval'}) fwd rel err {err:.2e}; speed {speed.item():.4f} vs {rspeed.item():.4f}")
+    assert err <= 2e-5
+    assert abs(speed.item() - rspeed.item()) <= 1e-4 * abs(rspeed.item())
+    assert m.get_current_blocks() == 2 and m.get_block_status() == [0, 2]
+    if not training:
+        return
+    (torch.nn.functional.l1_loss(out, hr.cuda()) + 0.1 * speed.sum()).backward()
+    (torch.nn.functional.l1_loss(ref, hr) + 0.1 * rspeed.sum()).backward()
+    worst = 0.0
+    for k, p in m.named_parameters():
+        rg = sd[k].grad
+        if rg is None or float(rg.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) <= 1e-7, k
+            continue
+        ge = (p.grad.cpu() - rg).abs().max().item() / rg.abs().max().item()
+        worst = max(worst, ge)
+        assert ge <= 5e-4, (k, ge)
+    print(f"NAS model worst param-grad rel err {worst:.2e}")
