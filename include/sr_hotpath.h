@@ -105,6 +105,12 @@ int sr_c3_bwd_data(const void* dA, const void* A, const void* add, void* dx, con
 int sr_c3_wgrad(const void* x, const void* dA, const void* A, float* partial, int wgs, int N, int H, int W,
                 int CI, int act, int dtype, sr_stream_t stream);
 
+/* flow_warp, models/spynet_arch.py:98-129 (bilinear, zeros padding, align_corners=True): x, out NCHW fp32;
+ * flow (N,H,W,2).  Backward: dx (zero-filled by the caller, may be NULL) and dflow (may be NULL). */
+int sr_flow_warp_fwd(const float* x, const float* flow, float* out, int N, int C, int H, int W, sr_stream_t stream);
+int sr_flow_warp_bwd(const float* x, const float* flow, const float* gout, float* dx, float* dflow, int N, int C,
+                     int H, int W, sr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * NAS supernet block: Split_Block.forward_body (models/wdsr_b.py:482-496) with Conv_sep branches
  * (:375-402), the BinaryConv2d masks (models/ops.py:7-43) and the hard skip/keep gate of

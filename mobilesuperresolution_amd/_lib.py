@@ -31,6 +31,8 @@ SIGNATURES = {
     "sr_c3_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_c3_bwd_data": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_c3_wgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    "sr_flow_warp_fwd": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "sr_flow_warp_bwd": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "sr_nas_dw_fwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "sr_nas_pw_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "sr_nas_pw_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),

@@ -6,6 +6,7 @@
 #include "wdsr_prep.h"
 #include "conv3x3.h"
 #include "nas_block.h"
+#include "flow_warp.h"
 
 extern "C" int sr_abi_version(void) { return 1; }
 
@@ -278,6 +279,27 @@ extern "C" int sr_c3_wgrad(const void* x, const void* dA, const void* A, float* 
   if (!A) A = dA;
   return dtype == SR_DTYPE_BF16 ? c3_wgrad_t<__bf16>(x, dA, A, partial, wgs, N, H, W, CI, act, (hipStream_t)stream)
                                 : c3_wgrad_t<float>(x, dA, A, partial, wgs, N, H, W, CI, act, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// flow_warp
+// ------------------------------------------------------------------------------------------
+extern "C" int sr_flow_warp_fwd(const float* x, const float* flow, float* out, int N, int C, int H, int W,
+                                sr_stream_t stream) {
+  if (!x || !flow || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
+  const int blocks = std::min((H * W + 255) / 256, 1024);
+  hipLaunchKernelGGL(flow_warp_fwd_kernel, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, x, flow, out, C, H, W);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int sr_flow_warp_bwd(const float* x, const float* flow, const float* gout, float* dx, float* dflow, int N,
+                                int C, int H, int W, sr_stream_t stream) {
+  if (!x || !flow || !gout || N <= 0 || C <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
+  const int blocks = std::min((H * W + 255) / 256, 1024);
+  hipLaunchKernelGGL(flow_warp_bwd_kernel, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, x, flow, gout, dx, dflow,
+                     C, H, W);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -74,3 +74,41 @@ def test_recurrent_propagation_matches_oracle():
     rb, rf = propagate(x, fl, -fl, tb, tf, O.flow_warp)
     for a, b in zip(ob + of, rb + rf):
         assert (a.cpu() - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+
+
+def test_g8_flow_warp_matches_reference(golden_dir):
+    from mobilesuperresolution_amd.models.spynet_arch import flow_warp
+    d = _load(golden_dir, "g8_flow_warp.npz")
+    x = d["x"].cuda().requires_grad_(True)
+    fl = d["flow"].cuda().requires_grad_(True)
+    y = flow_warp(x, fl)
+    assert (y.detach().cpu() - d["y"]).abs().max().item() <= 1e-5 * d["y"].abs().max().item()
+    y.backward(d["dy"].cuda())
+    assert (x.grad.cpu() - d["dx"]).abs().max().item() <= 1e-5 * d["dx"].abs().max().item()
+    assert (fl.grad.cpu() - d["dflow"]).abs().max().item() <= 2e-4 * d["dflow"].abs().max().item()
+    # integer flows are pure shifts with zero fill: bit-exact
+    xs = torch.rand(1, 3, 9, 11, device="cuda")
+    f = torch.zeros(1, 9, 11, 2, device="cuda")
+    f[..., 0], f[..., 1] = 2.0, -1.0
+    out = flow_warp(xs, f)
+    exp = torch.zeros_like(xs)
+    exp[:, :, 1:, :9] = xs[:, :, :8, 2:]
+    assert torch.allclose(out, exp, atol=1e-6)
+
+
+def test_recurrent_propagation_all_hip():
+    """propagate() with the HIP trunk AND the HIP flow_warp, vs the oracle on both."""
+    from mobilesuperresolution_amd.models import ConvResidualBlocks
+    from mobilesuperresolution_amd.models.basicvsr_arch import propagate
+    from mobilesuperresolution_amd.models.spynet_arch import flow_warp
+    torch.manual_seed(1)
+    fb, ff = ConvResidualBlocks(27, 24, 2, "fp32"), ConvResidualBlocks(27, 24, 2, "fp32")
+    sdb, sdf = fb.state_dict(), ff.state_dict()
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(2, 3, 3, 40, 36, generator=g)
+    fl = torch.rand(2, 2, 2, 40, 36, generator=g) * 4 - 2
+    ob, of = propagate(x.cuda(), fl.cuda(), -fl.cuda(), fb.cuda(), ff.cuda(), flow_warp)
+    rb, rf = propagate(x, fl, -fl, lambda t: O.conv_residual_blocks_forward(t, sdb, "main"),
+                       lambda t: O.conv_residual_blocks_forward(t, sdf, "main"), O.flow_warp)
+    for a, b in zip(ob + of, rb + rf):
+        assert (a.cpu() - b).abs().max().item() <= 5e-5 * b.abs().max().item()
