@@ -67,6 +67,11 @@ int sr_wdsr_block_wgrad(const void* x, const void* dy, const void* wblob, const 
                         int N, int H, int W, int F, int dtype,
                         long x_ls, long dy_ls, long w_ls, long c_ls, sr_stream_t stream);
 int sr_wdsr_block_slab_sizes(int F, int* slab_a, int* slab_b);
+/* Diagnostic (bf16, F=24): same as sr_wdsr_block_wgrad plus s_memrealtime stamps, stamps[2][layers*wgs][128]. */
+int sr_wdsr_block_wgrad_stamps(const void* x, const void* dy, const void* wblob, const float* cinit,
+                               float* partial_a, float* partial_b, int layers, int wgs_per_layer, int N, int H, int W,
+                               long x_ls, long dy_ls, long w_ls, long c_ls, unsigned long long* stamps,
+                               sr_stream_t stream);
 
 /* Head conv forward.  Replaces `x - image_mean` + self.head(x), models/basic_wdsr_b.py:86-87:
  * x NCHW fp32 [N,3,H,W] in [0,1] -> y NHWC [N,H,W,F].  wblob: packing.ends_tables()["head"]. */

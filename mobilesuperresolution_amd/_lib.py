@@ -22,6 +22,7 @@ SIGNATURES = {
     "sr_wdsr_block_fwd_repeat": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block_bwd_data": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block_wgrad": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P], _I),
+    "sr_wdsr_block_wgrad_stamps": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P, _P], _I),
     "sr_wdsr_block_slab_sizes": ([_I, _P, _P], _I),
     "sr_head_fwd": ([_P, _P, _P, _F, _I, _I, _I, _I, _I, _P], _I),
     "sr_tail_fwd": ([_P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P], _I),

@@ -306,10 +306,10 @@ __global__ __launch_bounds__(384) void nas_pw_bwd_kernel(const T* __restrict__ y
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-    atomicAdd(sk + 1024 + row, db[i]);
-    atomicAdd(sk + 1024 + 32 + row, rk[i]);
+    const float a = half_sum(db[i]), b = half_sum(rk[i]);
+    if (r == 0) { atomicAdd(sk + 1024 + row, a); atomicAdd(sk + 1024 + 32 + row, b); }
   }
-  if (k == 0) atomicAdd(slab + 3 * C::PWB_K, sxy);
+  { const float v = wave_sum(sxy); if (k == 0 && lane == 0) atomicAdd(slab + 3 * C::PWB_K, v); }
   __syncthreads();
   float* out = partial + (size_t)blockIdx.x * C::PWB_SLAB;
   for (int i = tid; i < C::PWB_SLAB; i += 384) out[i] = slab[i];

@@ -39,16 +39,16 @@ int launch_block_bwd_data(const void* x, const void* dy, void* dx, const void* w
 template <typename T, int F, int E, int L>
 int launch_block_wgrad(const void* x, const void* dy, const void* wblob, const float* cinit, float* pa, float* pb,
                        int layers, int wgs, int N, int H, int W, long x_ls, long dy_ls, long w_ls, long c_ls,
-                       hipStream_t st) {
+                       hipStream_t st, unsigned long long* stamps = nullptr) {
   typedef BlockCfg<F, E, L> C;
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
   dim3 grid(wgs, layers);
   hipLaunchKernelGGL((wdsr_block_wgrad_kernel<T, F, E, L, 0>), grid, dim3(64 * WgradCfg<F, E, L, 0>::NWAVES), 0, st,
                      (const T*)x, (const T*)dy, (const T*)wblob, cinit, pa, N, H, W, tiles_x, tiles_x * tiles_y, x_ls,
-                     dy_ls, w_ls, c_ls);
+                     dy_ls, w_ls, c_ls, stamps);
   hipLaunchKernelGGL((wdsr_block_wgrad_kernel<T, F, E, L, 1>), grid, dim3(64 * WgradCfg<F, E, L, 1>::NWAVES), 0, st,
                      (const T*)x, (const T*)dy, (const T*)wblob, cinit, pb, N, H, W, tiles_x, tiles_x * tiles_y, x_ls,
-                     dy_ls, w_ls, c_ls);
+                     dy_ls, w_ls, c_ls, stamps ? stamps + (size_t)layers * wgs * 128 : nullptr);
   SR_HIP_CHECK_LAUNCH();
   return 0;
 }
@@ -100,6 +100,14 @@ extern "C" int sr_wdsr_block_wgrad(const void* x, const void* dy, const void* wb
   if (F == 32 && dtype == SR_DTYPE_F32) return SR_WG(float, 32, 192, 26);
 #undef SR_WG
   return -1;
+}
+
+extern "C" int sr_wdsr_block_wgrad_stamps(const void* x, const void* dy, const void* wblob, const float* cinit,
+                                          float* pa, float* pb, int layers, int wgs, int N, int H, int W, long x_ls,
+                                          long dy_ls, long w_ls, long c_ls, unsigned long long* stamps,
+                                          sr_stream_t stream) {
+  return launch_block_wgrad<__bf16, 24, 144, 20>(x, dy, wblob, cinit, pa, pb, layers, wgs, N, H, W, x_ls, dy_ls, w_ls,
+                                                 c_ls, (hipStream_t)stream, stamps);
 }
 
 extern "C" int sr_wdsr_block_slab_sizes(int F, int* slab_a, int* slab_b) {
@@ -183,7 +191,7 @@ extern "C" int sr_tail_wgrad(const float* dout, const void* feat, const float* x
   if (!dout || !feat || !x || !partial || wgs <= 0 || N <= 0 || H <= 0 || W <= 0) return -2;
   hipStream_t st = (hipStream_t)stream;
 #define CALLR(T, F_, R_) { typedef EndsCfg<F_, R_> E; const int tx = (W + E::TW - 1) / E::TW, tpi = tx * ((H + E::TH - 1) / E::TH); \
-    hipLaunchKernelGGL((sr_tail_wgrad_kernel<T, F_, R_>), dim3(wgs, 3), dim3(256), 0, st, dout, (const T*)feat, x, mean, partial, N, H, W, tx, tpi); }
+    hipLaunchKernelGGL((sr_tail_wgrad_kernel<T, F_, R_>), dim3(wgs), dim3(896), 0, st, dout, (const T*)feat, x, mean, partial, N, H, W, tx, tpi); }
 #define CALL(T, F_) SR_DISPATCH_R(CALLR, T, F_)
   SR_DISPATCH_TF(CALL)
 #undef CALL
@@ -197,7 +205,7 @@ extern "C" int sr_head_wgrad(const void* dy0, const float* x, float mean, float*
   if (!dy0 || !x || !partial || wgs <= 0 || N <= 0 || H <= 0 || W <= 0) return -2;
   hipStream_t st = (hipStream_t)stream;
 #define CALL(T, F_) { typedef EndsCfg<F_, 4> E; const int tx = (W + E::TW - 1) / E::TW, tpi = tx * ((H + E::TH - 1) / E::TH); \
-    hipLaunchKernelGGL((sr_head_wgrad_kernel<T, F_>), dim3(wgs), dim3(256), 0, st, (const T*)dy0, x, mean, partial, N, H, W, tx, tpi); }
+    hipLaunchKernelGGL((sr_head_wgrad_kernel<T, F_>), dim3(wgs), dim3(576), 0, st, (const T*)dy0, x, mean, partial, N, H, W, tx, tpi); }
   SR_DISPATCH_TF(CALL)
 #undef CALL
   SR_HIP_CHECK_LAUNCH();

@@ -168,6 +168,20 @@ SR_DEV typename FragOf<T>::type tr_frag(const T* img, int s, int lane, RowBase r
   return f;
 }
 
+// sum over the 32 lanes of each wave half (lanes that share hh); every lane of the half gets the total
+SR_DEV float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// accumulator tile -> [reg i][lane] floats of a slab (LDS or global), plain stores.  LDS float atomics
+// (ds_add_f32) measured ~1500 cycles per wave-instruction on gfx950: never reduce through them.
+SR_DEV void slab_store_tile(float* slab, int tile, const f32x16& acc, int lane) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) slab[(tile * 16 + i) * 64 + lane] = acc[i];
+}
+
 // accumulator tile -> [reg i][lane] floats in an LDS slab (atomic add: several waves share the slab)
 SR_DEV void slab_add_tile(float* slab, int tile, const f32x16& acc, int lane) {
 #pragma unroll

@@ -402,10 +402,13 @@ template <typename T, int F, int E, int L, int ROLE>
 __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_block_wgrad_kernel(
     const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ wblob,
     const float* __restrict__ cinit, float* __restrict__ partial, int N, int H, int W, int tiles_x,
-    int tiles_per_img, long x_ls, long dy_ls, long w_ls, long c_ls) {
+    int tiles_per_img, long x_ls, long dy_ls, long w_ls, long c_ls, unsigned long long* __restrict__ stamps) {
   typedef BlockCfg<F, E, L> C;
   typedef BwdCfg<C> B;
   typedef WgradCfg<F, E, L, ROLE> G;
+  int stamp_i = 0;
+#define SR_STAMP() do { if (stamps && threadIdx.x == 0 && stamp_i < 120) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 128 + stamp_i++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  SR_STAMP();
   typedef typename FragOf<T>::type FragT;
   constexpr int NTHREADS = 64 * G::NWAVES;
   constexpr bool WLDS = (sizeof(T) == 2);
@@ -417,7 +420,8 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
   constexpr int SLAB = ROLE == 0 ? B::SLAB_A : B::SLAB_B;
   constexpr int STAGE_ELEMS = B::DY_ELEMS + B::XC_ELEMS + IMG_ELEMS;
   constexpr int STAGE_BYTES = (STAGE_ELEMS + NWL * 512) * (int)sizeof(T);
-  constexpr int LDS_BYTES = STAGE_BYTES > SLAB * 4 ? STAGE_BYTES : SLAB * 4;
+  constexpr int RED_BYTES = ROLE == 0 ? (2 * SLAB + 9 * 32) * 4 : 0;   // ROLE 0: two half-slabs + per-wave db2 rows
+  constexpr int LDS_BYTES = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
   constexpr bool DB2_REGS = (sizeof(T) == 2);       // fp32 parity mode keeps db2 in LDS (register budget)
   __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES + 128];
   T* const DYs = reinterpret_cast<T*>(smem_raw);
@@ -456,8 +460,11 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
     const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
     const size_t img = (size_t)n * H * W * F;
     __syncthreads();
+    SR_STAMP();
     stage_bwd_tiles<T, C, NTHREADS>(DYs, XC, dy + img, x + img, H, W, ty0, tx0, tid);
+    SR_STAMP();
     __syncthreads();
+    SR_STAMP();
 
     // ---- phase 1: dt (ROLE 0) or t (ROLE 1) of one pixel tile per wave -> LDS image (zero outside the image) ----
     if (wave < C::NPT_O) {
@@ -474,7 +481,10 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
           for (int i = 0; i < 16; ++i) db2acc[i] += dtacc[i];
         } else {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) atomicAdd(db2lds + (i & 3) + 8 * (i >> 2) + 4 * hh, dtacc[i]);
+          for (int i = 0; i < 16; ++i) {
+            const float v = half_sum(dtacc[i]);
+            if (r == 0) atomicAdd(db2lds + (i & 3) + 8 * (i >> 2) + 4 * hh, v);
+          }
         }
         scratch_store<T>(IMG + (pc - r) * 32, dtacc, true, r, hh);
       } else {
@@ -485,7 +495,9 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
         scratch_store<T>(IMG + (pc - r) * 32, tacc, valid, r, hh);
       }
     }
+    SR_STAMP();
     __syncthreads();
+    SR_STAMP();
 
     // ---- phase 2 ----
     if constexpr (ROLE == 0) {
@@ -537,30 +549,52 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
         accA = mma16<T>(tr_frag<T>(IMG, 1, lane, rowi), tr_frag<T>(DYs, 1, lane, rowd), accA);
       }
     }
+    SR_STAMP();
   }
 
-  // ---- reduce through an LDS slab, then one coalesced store per workgroup ----
-  __syncthreads();
-  float* slab = reinterpret_cast<float*>(smem_raw);
-  for (int i = tid; i < SLAB; i += NTHREADS) slab[i] = 0.f;
-  __syncthreads();
+  // ---- combine the two waves of each e-tile through plain LDS stores (no LDS atomics), one coalesced
+  //      store per workgroup.  ROLE 1: every tile has a single owner wave -> straight to HBM. ----
+  float* out = partial + ((size_t)layer * gridDim.x + blockIdx.x) * SLAB;
   if constexpr (ROLE == 0) {
-    slab_add_tile(slab, et, accA, lane);
-    slab_add_tile(slab, C::NET + et, accB, lane);
-    atomicAdd(slab + 2 * C::NET * 1024 + et * 32 + r, db1);
+    float db2keep = 0.f;
+    if constexpr (!DB2_REGS) { if (tid < 32) db2keep = db2lds[tid]; }
+    __syncthreads();
+    SR_STAMP();
+    float* red = reinterpret_cast<float*>(smem_raw);
+    float* mine = red + half * SLAB;
+    float* db2w = red + 2 * SLAB;
+    slab_store_tile(mine, et, accA, lane);
+    slab_store_tile(mine, C::NET + et, accB, lane);
+    const float d1 = db1 + __shfl_xor(db1, 32);
+    if (hh == 0) mine[2 * C::NET * 1024 + et * 32 + r] = d1;
     if constexpr (DB2_REGS) {
       if (wave < C::NPT_O) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-          atomicAdd(slab + 2 * C::NET * 1024 + C::NET * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh, db2acc[i]);
+        for (int i = 0; i < 16; ++i) {
+          const float v = half_sum(db2acc[i]);
+          if (r == 0) db2w[wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh] = v;
+        }
       }
-    } else {
-      if (tid < 32) atomicAdd(slab + 2 * C::NET * 1024 + C::NET * 32 + tid, db2lds[tid]);
     }
+    __syncthreads();
+    SR_STAMP();
+    constexpr int NSUM = 2 * C::NET * 1024 + C::NET * 32;
+    for (int i = tid; i < NSUM; i += NTHREADS) out[i] = red[i] + red[SLAB + i];
+    if (tid < 32) {
+      float v = db2keep;
+      if constexpr (DB2_REGS) {
+#pragma unroll
+        for (int w = 0; w < C::NPT_O; ++w) v += db2w[w * 32 + tid];
+      }
+      out[NSUM + tid] = v;
+    }
+    SR_STAMP();
   } else {
-    slab_add_tile(slab, wave, accA, lane);
+    SR_STAMP();
+    SR_STAMP();
+    slab_store_tile(out, wave, accA, lane);
+    SR_STAMP();
   }
-  __syncthreads();
-  float* out = partial + ((size_t)layer * gridDim.x + blockIdx.x) * SLAB;
-  for (int i = tid; i < SLAB; i += NTHREADS) out[i] = slab[i];
+  SR_STAMP();
+#undef SR_STAMP
 }

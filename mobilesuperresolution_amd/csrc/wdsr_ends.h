@@ -39,12 +39,12 @@ template <typename T> SR_DEV typename FragOf<T>::type lds_chunk_half(const T* im
   return f;
 }
 
-template <typename T, typename E, int P>
+template <typename T, typename E, int P, int NTHREADS = 256>
 SR_DEV void stage_img(T* XI, const float* __restrict__ ximg, float mean, int H, int W, int ty0, int tx0, int tid) {
   typedef typename FragOf<T>::half_type HalfT;
   typedef typename E::template Img<P> I;
   const size_t plane = (size_t)H * W;
-  for (int ip = tid; ip < I::NPI + 8; ip += 256) {
+  for (int ip = tid; ip < I::NPI + 8; ip += NTHREADS) {
     HalfT v;
     v[0] = (T)0.f; v[1] = (T)0.f; v[2] = (T)0.f; v[3] = (T)1.f;
     if (ip < I::NPI) {
@@ -62,11 +62,11 @@ SR_DEV void stage_img(T* XI, const float* __restrict__ ximg, float mean, int H, 
 }
 
 // feature / gradient tile with a 1-pixel halo: [NPXH_PAD + 2][CH] (CH multiple of 8), zero outside
-template <typename T, typename E, int CH>
+template <typename T, typename E, int CH, int NTHREADS = 256>
 SR_DEV void stage_halo(T* dst, const T* __restrict__ src, int H, int W, int ty0, int tx0, int tid) {
   typedef typename FragOf<T>::type FragT;
   constexpr int NC = CH / 8;
-  for (int idx = tid; idx < (E::NPXH_PAD + 2) * NC; idx += 256) {
+  for (int idx = tid; idx < (E::NPXH_PAD + 2) * NC; idx += NTHREADS) {
     const int hp = idx / NC, c = idx - hp * NC;
     FragT v;
 #pragma unroll
@@ -80,11 +80,11 @@ SR_DEV void stage_halo(T* dst, const T* __restrict__ src, int H, int W, int ty0,
   }
 }
 
-template <typename T, typename E, int CH>
+template <typename T, typename E, int CH, int NTHREADS = 256>
 SR_DEV void stage_core(T* dst, const T* __restrict__ src, int H, int W, int ty0, int tx0, int tid) {
   typedef typename FragOf<T>::type FragT;
   constexpr int NC = CH / 8;
-  for (int idx = tid; idx < (E::NPXC + 2) * NC; idx += 256) {
+  for (int idx = tid; idx < (E::NPXC + 2) * NC; idx += NTHREADS) {
     const int pc = idx / NC, c = idx - pc * NC;
     FragT v;
 #pragma unroll
@@ -100,7 +100,7 @@ SR_DEV void stage_core(T* dst, const T* __restrict__ src, int H, int W, int ty0,
 // un-shuffle the HR gradient (NCHW fp32, N x 3 x RH x RW) into a dconv tile [px][COP]:
 // channel c*R*R + i*R + j of LR pixel (Y, X) = dout[c][Y*R + i][X*R + j].  HALO = 1: tile with halo,
 // HALO = 0: core tile.
-template <typename T, typename E, int HALO>
+template <typename T, typename E, int HALO, int NTHREADS = 256>
 SR_DEV void stage_dconv(T* DC, const float* __restrict__ dout, int H, int W, int ty0, int tx0, int tid) {
   constexpr int R = E::R;
   constexpr int NPX = HALO ? (E::NPXH_PAD + 2) : (E::NPXC + 2);
@@ -108,7 +108,7 @@ SR_DEV void stage_dconv(T* DC, const float* __restrict__ dout, int H, int W, int
   constexpr int TWW = HALO ? E::HW : E::TW;
   const size_t hrw = (size_t)W * R, plane = (size_t)H * R * hrw;
   constexpr int ROWS = 3 * R;                       // (colour, sub-row) pairs per pixel
-  for (int idx = tid; idx < NPX * ROWS; idx += 256) {
+  for (int idx = tid; idx < NPX * ROWS; idx += NTHREADS) {
     const int p = idx / ROWS, cr = idx - p * ROWS;
     const int c = cr / R, si = cr - c * R;
     float v[R];
@@ -139,7 +139,7 @@ SR_DEV void stage_dconv(T* DC, const float* __restrict__ dout, int H, int W, int
     }
   }
   if constexpr (E::COP > E::CO) {                    // zero the padding channels
-    for (int idx = tid; idx < NPX * (E::COP - E::CO); idx += 256) {
+    for (int idx = tid; idx < NPX * (E::COP - E::CO); idx += NTHREADS) {
       const int p = idx / (E::COP - E::CO), k = idx - p * (E::COP - E::CO);
       DC[p * E::COP + E::CO + k] = (T)0.f;
     }
@@ -306,143 +306,113 @@ __global__ __launch_bounds__(256) void sr_tail_bwd_data_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-// tail weight gradients.  blockIdx.y = role (0..2): role k owns the three taps of tail row ky = k and the
-// skip rows {0,1}, {2,3}, {4}; every accumulator tile is [conv channel rows, input columns], pixels
-// contracted through transposed LDS reads.  Slab: [TAIL_TILES][16][64] per workgroup (roles write
-// disjoint tiles); layout in packing.ends_grad_tables.
+// tail weight gradients.  14 waves: wave g < 9 owns tap g of the 3x3 tail conv, wave 9 + ky owns skip row ky;
+// each keeps its NT accumulator tiles [conv channel rows, input columns] in registers over every pixel
+// tile the workgroup walks (no cross-wave reduction), pixels contracted through transposed LDS reads.
+// Slab per workgroup: [TAIL_TILES][16][64]; layout in packing.ends_grad_tables.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int F, int R>
-__global__ __launch_bounds__(256, 1) void sr_tail_wgrad_kernel(const float* __restrict__ dout, const T* __restrict__ feat,
-                                                               const float* __restrict__ ximg, float mean,
-                                                               float* __restrict__ partial, int N, int H, int W,
-                                                               int tiles_x, int tiles_per_img) {
+__global__ __launch_bounds__(896) void sr_tail_wgrad_kernel(const float* __restrict__ dout, const T* __restrict__ feat,
+                                                            const float* __restrict__ ximg, float mean,
+                                                            float* __restrict__ partial, int N, int H, int W,
+                                                            int tiles_x, int tiles_per_img) {
   typedef EndsCfg<F, R> E;
   typedef typename E::template Img<2> I;
   typedef typename FragOf<T>::type FragT;
-  constexpr int NT = E::NT;
-  constexpr int MAXT = 5 * NT;                               // 3 taps + up to 2 skip rows
-  constexpr int STAGE_BYTES = (E::DCC_ELEMS + E::FT_ELEMS + I::ELEMS) * (int)sizeof(T);
-  constexpr int SLAB_BYTES = MAXT * 1024 * 4;
-  constexpr int LDS_BYTES = STAGE_BYTES > SLAB_BYTES ? STAGE_BYTES : SLAB_BYTES;
-  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES];
-  T* const DC = reinterpret_cast<T*>(smem_raw);
+  constexpr int NT = E::NT, NTHREADS = 896;
+  __shared__ __attribute__((aligned(16))) T smem[E::DCC_ELEMS + E::FT_ELEMS + I::ELEMS];
+  T* const DC = smem;
   T* const FT = DC + E::DCC_ELEMS;
   T* const XI = FT + E::FT_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int role = blockIdx.y;
-  const int sk0 = 2 * role, nsk = (role == 2) ? 1 : 2;       // skip rows sk0 .. sk0 + nsk - 1
+  const bool is_tap = wave < 9;
+  const int ty = is_tap ? wave / 3 : wave - 9, tx = is_tap ? wave % 3 : 0;
 
-  f32x16 acc[MAXT];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int i = 0; i < MAXT; ++i) acc[i] = zero16();
+  for (int i = 0; i < NT; ++i) acc[i] = zero16();
 
   for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
     const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
     const int ty0 = (tile / tiles_x) * E::TH, tx0 = (tile % tiles_x) * E::TW;
     __syncthreads();
-    stage_dconv<T, E, 0>(DC, dout + (size_t)n * 3 * H * R * W * R, H, W, ty0, tx0, tid);
-    stage_halo<T, E, F>(FT, feat + (size_t)n * H * W * F, H, W, ty0, tx0, tid);
-    stage_img<T, E, 2>(XI, ximg + (size_t)n * 3 * H * W, mean, H, W, ty0, tx0, tid);
+    stage_dconv<T, E, 0, NTHREADS>(DC, dout + (size_t)n * 3 * H * R * W * R, H, W, ty0, tx0, tid);
+    stage_halo<T, E, F, NTHREADS>(FT, feat + (size_t)n * H * W * F, H, W, ty0, tx0, tid);
+    stage_img<T, E, 2, NTHREADS>(XI, ximg + (size_t)n * 3 * H * W, mean, H, W, ty0, tx0, tid);
     __syncthreads();
-    for (int ot = wave; ot < E::NPT_O; ot += 4) {
+    constexpr int UNR = sizeof(T) == 2 ? 3 : 1;
+#pragma unroll UNR
+    for (int ot = 0; ot < E::NPT_O; ++ot) {
       const int toy = (ot / (E::TW / 8)) * 4, tox = (ot % (E::TW / 8)) * 8;
-      FragT dcT[NT][2];
 #pragma unroll
-      for (int ti = 0; ti < NT; ++ti)
+      for (int s = 0; s < 2; ++s) {
+        FragT b;
+        if (is_tap) b = tr_frag<T>(FT, s, lane, [=](int p) { return ((toy + (p >> 3) + ty) * E::HW + tox + (p & 7) + tx) * F; });
+        else b = tr_frag<T>(XI, s, lane, [=](int p) { return ((toy + (p >> 3) + ty) * I::IW + tox + (p & 7)) * 4; });
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-          dcT[ti][s] = tr_frag<T>(DC, s, lane, [=](int p) { return ((toy + (p >> 3)) * E::TW + tox + (p & 7)) * E::COP + 32 * ti; });
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const FragT b = tr_frag<T>(FT, s, lane, [=](int p) {
-            return ((toy + (p >> 3) + role) * E::HW + tox + (p & 7) + kx) * F;
-          });
-#pragma unroll
-          for (int ti = 0; ti < NT; ++ti) acc[kx * NT + ti] = mma16<T>(dcT[ti][s], b, acc[kx * NT + ti]);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        if (k < nsk) {
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const FragT b = tr_frag<T>(XI, s, lane, [=](int p) {
-              return ((toy + (p >> 3) + sk0 + k) * I::IW + tox + (p & 7)) * 4;
-            });
-#pragma unroll
-            for (int ti = 0; ti < NT; ++ti) acc[(3 + k) * NT + ti] = mma16<T>(dcT[ti][s], b, acc[(3 + k) * NT + ti]);
-          }
+        for (int ti = 0; ti < NT; ++ti) {
+          const FragT a = tr_frag<T>(DC, s, lane, [=](int p) { return ((toy + (p >> 3)) * E::TW + tox + (p & 7)) * E::COP + 32 * ti; });
+          acc[ti] = mma16<T>(a, b, acc[ti]);
         }
       }
     }
   }
-  __syncthreads();
-  float* slab = reinterpret_cast<float*>(smem_raw);
-  for (int i = tid; i < MAXT * 1024; i += 256) slab[i] = 0.f;
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < MAXT; ++i) slab_add_tile(slab, i, acc[i], lane);
-  __syncthreads();
+  // global tile index: taps (ty*3 + tx)*NT + ti ; skip rows 9*NT + ky*NT + ti
   float* out = partial + (size_t)blockIdx.x * E::TAIL_TILES * 1024;
-  // local tile i -> global tile: taps (role*3 + kx)*NT + ti ; skip rows 9*NT + (sk0 + k)*NT + ti
-  const int nloc = (3 + nsk) * NT;
-  for (int i = tid; i < nloc * 1024; i += 256) {
-    const int lt = i >> 10, w = i & 1023;
-    const int grp = lt / NT, ti = lt - grp * NT;
-    const int gt = (grp < 3) ? ((role * 3 + grp) * NT + ti) : (9 * NT + (sk0 + grp - 3) * NT + ti);
-    out[gt * 1024 + w] = slab[i];
-  }
+  const int gbase = is_tap ? (ty * 3 + tx) * NT : (9 + ty) * NT;
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[((gbase + ti) * 16 + i) * 64 + lane] = acc[ti][i];
 }
 
 // ---------------------------------------------------------------------------------------------
-// head weight gradient: tiles [ky] = [f rows, (kx, ci) columns], dy0 = gradient w.r.t. the head output
+// head weight gradient: tiles [ky] = [f rows, (kx, ci) columns], dy0 = gradient w.r.t. the head output.
+// 9 waves: wave (ky, grp) owns tile ky over the pixel tiles grp, grp+3, grp+6.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int F>
-__global__ __launch_bounds__(256, 1) void sr_head_wgrad_kernel(const T* __restrict__ dy0, const float* __restrict__ ximg,
-                                                               float mean, float* __restrict__ partial, int N, int H,
-                                                               int W, int tiles_x, int tiles_per_img) {
+__global__ __launch_bounds__(576) void sr_head_wgrad_kernel(const T* __restrict__ dy0, const float* __restrict__ ximg,
+                                                            float mean, float* __restrict__ partial, int N, int H,
+                                                            int W, int tiles_x, int tiles_per_img) {
   typedef EndsCfg<F, 4> E;
   typedef typename E::template Img<1> I;
   typedef typename FragOf<T>::type FragT;
+  constexpr int NTHREADS = 576;
   constexpr int STAGE_BYTES = (E::DYC_ELEMS + I::ELEMS) * (int)sizeof(T);
-  constexpr int SLAB_BYTES = 3 * 1024 * 4;
+  constexpr int SLAB_BYTES = 9 * 1024 * 4;
   constexpr int LDS_BYTES = STAGE_BYTES > SLAB_BYTES ? STAGE_BYTES : SLAB_BYTES;
   __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES];
   T* const DY = reinterpret_cast<T*>(smem_raw);
   T* const XI = DY + E::DYC_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  f32x16 acc[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) acc[i] = zero16();
+  const int ky = wave / 3, grp = wave - ky * 3;
+  f32x16 acc = zero16();
   for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
     const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
     const int ty0 = (tile / tiles_x) * E::TH, tx0 = (tile % tiles_x) * E::TW;
     __syncthreads();
-    stage_core<T, E, F>(DY, dy0 + (size_t)n * H * W * F, H, W, ty0, tx0, tid);
-    stage_img<T, E, 1>(XI, ximg + (size_t)n * 3 * H * W, mean, H, W, ty0, tx0, tid);
+    stage_core<T, E, F, NTHREADS>(DY, dy0 + (size_t)n * H * W * F, H, W, ty0, tx0, tid);
+    stage_img<T, E, 1, NTHREADS>(XI, ximg + (size_t)n * 3 * H * W, mean, H, W, ty0, tx0, tid);
     __syncthreads();
-    for (int ot = wave; ot < E::NPT_O; ot += 4) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int ot = grp + 3 * k;
       const int toy = (ot / (E::TW / 8)) * 4, tox = (ot % (E::TW / 8)) * 8;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const FragT a = tr_frag<T>(DY, s, lane, [=](int p) { return ((toy + (p >> 3)) * E::TW + tox + (p & 7)) * F; });
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const FragT b = tr_frag<T>(XI, s, lane, [=](int p) { return ((toy + (p >> 3) + ky) * I::IW + tox + (p & 7)) * 4; });
-          acc[ky] = mma16<T>(a, b, acc[ky]);
-        }
+        const FragT b = tr_frag<T>(XI, s, lane, [=](int p) { return ((toy + (p >> 3) + ky) * I::IW + tox + (p & 7)) * 4; });
+        acc = mma16<T>(a, b, acc);
       }
     }
   }
   __syncthreads();
-  float* slab = reinterpret_cast<float*>(smem_raw);
-  for (int i = tid; i < 3 * 1024; i += 256) slab[i] = 0.f;
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 3; ++i) slab_add_tile(slab, i, acc[i], lane);
+  float* slab = reinterpret_cast<float*>(smem_raw);           // [ky][grp][1024]: plain stores, no LDS atomics
+  slab_store_tile(slab, wave, acc, lane);
   __syncthreads();
   float* out = partial + (size_t)blockIdx.x * 3 * 1024;
-  for (int i = tid; i < 3 * 1024; i += 256) out[i] = slab[i];
+  for (int i = tid; i < 3 * 1024; i += NTHREADS) {
+    const int k = i >> 10, w = i & 1023;
+    out[i] = slab[(3 * k) * 1024 + w] + slab[(3 * k + 1) * 1024 + w] + slab[(3 * k + 2) * 1024 + w];
+  }
 }
