@@ -190,6 +190,59 @@ template <typename C> struct BwdCfg {
   static constexpr int SLAB_B = 9 * 1024;
 };
 
+// register-staged form of the same tiles: load() issues every global load, store() writes LDS later, so a
+// persistent kernel can fetch tile t+1 from HBM while it computes on tile t (double-buffered LDS).
+template <typename T, typename C, int NTHREADS> struct BwdTileRegs {
+  typedef typename FragOf<T>::type FragT;
+  static constexpr int CHX = C::KX / 8, NPXC = C::TH * C::TW;
+  static constexpr int TD = (C::NPXH_PAD + 2) * C::FC, TX = (NPXC + 1) * CHX;
+  static constexpr int ID = (TD + NTHREADS - 1) / NTHREADS, IX = (TX + NTHREADS - 1) / NTHREADS;
+  FragT vd[ID], vx[IX];
+  SR_DEV void load(const T* __restrict__ din, const T* __restrict__ xin, int H, int W, int ty0, int tx0, int tid) {
+#pragma unroll
+    for (int it = 0; it < ID; ++it) {
+      const int idx = tid + it * NTHREADS;
+      const int hp = idx / C::FC, c = idx - hp * C::FC;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vd[it][j] = (T)0.f;
+      if (idx < TD && hp < C::NPXH) {
+        const int hy = hp / C::HW, hx = hp - hy * C::HW;
+        const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
+        if (Y >= 0 && Y < H && X >= 0 && X < W) vd[it] = *reinterpret_cast<const FragT*>(din + ((size_t)Y * W + X) * C::F + c * 8);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < IX; ++it) {
+      const int idx = tid + it * NTHREADS;
+      const int pc = idx / CHX, c = idx - pc * CHX;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vx[it][j] = (T)0.f;
+      if (idx < TX) {
+        if (c < C::FC) {
+          if (pc < NPXC) {
+            const int Y = ty0 + pc / C::TW, X = tx0 + pc % C::TW;
+            if (Y < H && X < W) vx[it] = *reinterpret_cast<const FragT*>(xin + ((size_t)Y * W + X) * C::F + c * 8);
+          }
+        } else if (C::FOLD_B1 && c == C::FC) {
+          vx[it][0] = (T)1.f;
+        }
+      }
+    }
+  }
+  SR_DEV void store(T* DYs, T* XC, int tid) const {
+#pragma unroll
+    for (int it = 0; it < ID; ++it) {
+      const int idx = tid + it * NTHREADS;
+      if (idx < TD) *reinterpret_cast<FragT*>(DYs + idx * 8) = vd[it];
+    }
+#pragma unroll
+    for (int it = 0; it < IX; ++it) {
+      const int idx = tid + it * NTHREADS;
+      if (idx < TX) *reinterpret_cast<FragT*>(XC + idx * 8) = vx[it];
+    }
+  }
+};
+
 // backward tiles: dy with a 1-pixel halo [NPXH_PAD + 2][F] and the core x tile [NPXC + 1][KX]; every
 // global load of both is issued before the first LDS store.
 template <typename T, typename C, int NTHREADS>
@@ -418,24 +471,30 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
   constexpr int LW3T = WLDS ? NW1 : B::W3T_OFF, LW2N = WLDS ? NW1 + B::KS3B : B::W2N_OFF;
   constexpr int NWL = !WLDS ? 0 : (ROLE == 0 ? NW1 + B::KS3B + 2 * C::NET : C::W3_OFF);
   constexpr int SLAB = ROLE == 0 ? B::SLAB_A : B::SLAB_B;
-  constexpr int STAGE_ELEMS = B::DY_ELEMS + B::XC_ELEMS + IMG_ELEMS;
-  constexpr int STAGE_BYTES = (STAGE_ELEMS + NWL * 512) * (int)sizeof(T);
+  constexpr int TILE_ELEMS = B::DY_ELEMS + B::XC_ELEMS;               // one (dy halo, x core) buffer
+  constexpr int CIN_BYTES = ((B::CINIT + 3) / 4) * 16;                // C-init tables, copied to LDS
+  // double-buffer the tile staging when two buffers fit beside the image and the weights (bf16 only)
+  constexpr bool DBUF = WLDS && !(ROLE == 0 && F > 24) &&   // (F = 32, ROLE 0: the prefetch registers do not fit the 168 budget)
+                        ((2 * TILE_ELEMS + IMG_ELEMS + NWL * 512) * (int)sizeof(T) + CIN_BYTES + 256 <= 160 * 1024);
+  constexpr int STAGE_ELEMS = (DBUF ? 2 : 1) * TILE_ELEMS + IMG_ELEMS;
+  constexpr int STAGE_BYTES = (STAGE_ELEMS + NWL * 512) * (int)sizeof(T) + CIN_BYTES;
   constexpr int RED_BYTES = ROLE == 0 ? (2 * SLAB + 9 * 32) * 4 : 0;   // ROLE 0: two half-slabs + per-wave db2 rows
   constexpr int LDS_BYTES = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
   constexpr bool DB2_REGS = (sizeof(T) == 2);       // fp32 parity mode keeps db2 in LDS (register budget)
   __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES + 128];
-  T* const DYs = reinterpret_cast<T*>(smem_raw);
-  T* const XC = DYs + B::DY_ELEMS;
-  T* const IMG = XC + B::XC_ELEMS;
+  T* const BUF = reinterpret_cast<T*>(smem_raw);                       // [DBUF ? 2 : 1][TILE_ELEMS]
+  T* const IMG = BUF + (DBUF ? 2 : 1) * TILE_ELEMS;
+  float* const cls = reinterpret_cast<float*>(smem_raw + (STAGE_ELEMS + NWL * 512) * sizeof(T));
   float* const db2lds = reinterpret_cast<float*>(smem_raw + LDS_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   if (tid < 32) db2lds[tid] = 0.f;
 
   const int layer = blockIdx.y;
   x += (size_t)layer * x_ls; dy += (size_t)layer * dy_ls; wblob += (size_t)layer * w_ls; cinit += (size_t)layer * c_ls;
+  for (int i = tid; i < B::CINIT; i += NTHREADS) cls[i] = cinit[i];     // no global load inside the tile loop
   WSrc<T, WLDS> wsrc;
   if constexpr (WLDS) {
-    T* wl = DYs + STAGE_ELEMS;
+    T* wl = BUF + STAGE_ELEMS;
     if constexpr (ROLE == 0) {
       stage_weights<T, NTHREADS>(wl, wblob, NW1, tid);
       stage_weights<T, NTHREADS>(wl + NW1 * 512, wblob + (size_t)B::W3T_OFF * 512, B::KS3B, tid);
@@ -455,15 +514,29 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
   float db1 = 0.f;
   const int et = wave >> 1, half = wave & 1;
 
-  for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
+  const int total = N * tiles_per_img;
+  BwdTileRegs<T, C, NTHREADS> regs;
+  auto fetch = [&](int t) {
+    const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
+    const size_t img = (size_t)n * H * W * F;
+    int tid2 = tid;                                    // recompute the per-thread tile indices every time:
+    asm volatile("" : "+v"(tid2));                     // hoisted, they are spilled around the tile loop
+    regs.load(dy + img, x + img, H, W, (tile / tiles_x) * C::TH, (tile % tiles_x) * C::TW, tid2);
+  };
+  int cur = 0;
+  if ((int)blockIdx.x < total) fetch(blockIdx.x);
+  __syncthreads();
+  if ((int)blockIdx.x < total) regs.store(BUF, BUF + B::DY_ELEMS, tid);
+  for (int t = blockIdx.x; t < total; t += gridDim.x) {
     const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
     const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
-    const size_t img = (size_t)n * H * W * F;
-    __syncthreads();
+    const bool has_next = t + (int)gridDim.x < total;
+    T* const DYs = BUF + cur * TILE_ELEMS;
+    T* const XC = DYs + B::DY_ELEMS;
     SR_STAMP();
-    stage_bwd_tiles<T, C, NTHREADS>(DYs, XC, dy + img, x + img, H, W, ty0, tx0, tid);
+    __syncthreads();                                   // tile t staged; IMG free
     SR_STAMP();
-    __syncthreads();
+    if (DBUF && has_next) fetch(t + gridDim.x);        // HBM loads of tile t+1 fly during the compute below
     SR_STAMP();
 
     // ---- phase 1: dt (ROLE 0) or t (ROLE 1) of one pixel tile per wave -> LDS image (zero outside the image) ----
@@ -474,7 +547,7 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
       const int hbase = oy * C::HW + ox, pc = oy * C::TW + ox;
       const bool valid = (ty0 + oy < H) && (tx0 + ox < W);
       if constexpr (ROLE == 0) {
-        f32x16 dtacc = dt_tile<T, C, WSrc<T, WLDS>, (sizeof(T) == 2 ? 64 : 1)>(DYs, wsrc, LW3T, hbase, lane);
+        f32x16 dtacc = dt_tile<T, C, WSrc<T, WLDS>, (sizeof(T) == 2 ? 4 : 1)>(DYs, wsrc, LW3T, hbase, lane);
         if (!valid) dtacc = zero16();
         if constexpr (DB2_REGS) {
 #pragma unroll
@@ -491,7 +564,7 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
         FragT xb[C::KS1];
 #pragma unroll
         for (int s = 0; s < C::KS1; ++s) xb[s] = lds_chunk<T>(XC, pc * C::KX + (2 * s + hh) * 8);
-        const f32x16 tacc = t_tile<T, C, WSrc<T, WLDS>, (sizeof(T) == 2 ? 64 : 1)>(xb, wsrc, cinit, lane);
+        const f32x16 tacc = t_tile<T, C, WSrc<T, WLDS>, (sizeof(T) == 2 ? 64 : 1)>(xb, wsrc, cls, lane);
         scratch_store<T>(IMG + (pc - r) * 32, tacc, valid, r, hh);
       }
     }
@@ -502,8 +575,7 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
     // ---- phase 2 ----
     if constexpr (ROLE == 0) {
       wsrc.tile();
-      constexpr int UNR2 = sizeof(T) == 2 ? 2 : 1;
-#pragma unroll UNR2
+#pragma unroll 1
       for (int ot = half; ot < C::NPT_O; ot += 2) {
         const int toy = (ot / (C::TW / 8)) * 4, tox = (ot % (C::TW / 8)) * 8;
         const int pc = (toy + (r >> 3)) * C::TW + tox + (r & 7);
@@ -513,7 +585,7 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
         if (C::FOLD_B1) {
           h2 = zero16();
         } else {
-          const float b = cinit[B::B1N_OFF + et * 32 + r];
+          const float b = cls[B::B1N_OFF + et * 32 + r];
 #pragma unroll
           for (int i = 0; i < 16; ++i) h2[i] = b;
         }
@@ -550,6 +622,16 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
       }
     }
     SR_STAMP();
+    if (has_next) {
+      if constexpr (DBUF) {
+        cur ^= 1;
+        regs.store(BUF + cur * TILE_ELEMS, BUF + cur * TILE_ELEMS + B::DY_ELEMS, tid);
+      } else {
+        __syncthreads();                               // everyone done with the single buffer
+        fetch(t + gridDim.x);
+        regs.store(BUF, BUF + B::DY_ELEMS, tid);
+      }
+    }
   }
 
   // ---- combine the two waves of each e-tile through plain LDS stores (no LDS atomics), one coalesced

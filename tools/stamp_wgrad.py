@@ -20,7 +20,7 @@ s = st.cpu().numpy().reshape(2, nb * wgs, 128).astype(np.float64) * 10.0
 for role in range(2):
     a = s[role]
     print(f"ROLE {role}: kernel span {a[:, :100].max() - a[:, 0].min():.0f} ns; prologue (weights) {np.mean(a[:,1]-a[:,0]):.0f} ns")
-    names = ["stage", "barrier", "phase1", "barrier", "phase2", "loop-top barrier"]
+    names = ["top barrier wait", "issue prefetch", "phase1", "barrier", "phase2", "store next + loop"]
     tiles = 16
     per = np.zeros(6)
     for t in range(tiles):
