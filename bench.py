@@ -190,9 +190,13 @@ def main():
             step()
         L.set_timer(None)
         calls = {k: round(v[1] * 1e3, 1) for k, v in timer.summary().items()}
+        traffic = None                                   # PMC bytes per launch, collected offline with rocprofv3 --pmc
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_block_fwd.json")
+        if args.dtype == "bf16" and os.path.exists(pmc):
+            traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
         roofline = {"kernel": f"wdsr_block_fwd_kernel<{args.dtype},24,144,20>", "bound": "hbm",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "alg_bytes_per_launch": alg["sr_wdsr_block_fwd"], "avg_launch_us": round(us, 2),
                     "how": f"{reps} back-to-back launches from one C call, HIP events on the launch stream "
                            "(includes inter-launch gaps)"}

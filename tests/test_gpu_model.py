@@ -169,3 +169,91 @@ def test_ddp_rccl_single_rank_step():
         assert len(ddp.state_dict()) == 3 * (3 * 2 + 3) and "module.skip.0.weight_v" in ddp.state_dict()
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------
+# edge cases and the other BASELINE configs
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 5, 7), (2, 12, 24), (1, 13, 25), (3, 48, 48), (1, 37, 91)])
+def test_ragged_and_tiny_images_vs_oracle(shape):
+    """images smaller than / not a multiple of the 12x24 workgroup tile, batch 1..3"""
+    n, h, w = shape
+    torch.manual_seed(11)
+    ns = _ns(num_blocks=2)
+    m = _model(ns).train()
+    ref = O.OracleBasicModel(ns)
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()}, strict=True)
+    x = torch.rand(n, 3, h, w)
+    hr = torch.rand(n, 3, 4 * h, 4 * w)
+    y = m(x.cuda())
+    yr = ref(x)
+    assert (y.detach().cpu() - yr.detach()).abs().max().item() <= 2e-5 * yr.abs().max().item()
+    torch.nn.functional.l1_loss(y, hr.cuda()).backward()
+    torch.nn.functional.l1_loss(yr, hr).backward()
+    refg = dict(ref.named_parameters())
+    gflat = m.flat.grad.cpu()
+    for k, (off, shp) in m.layout.entries.items():
+        e = (gflat[off:off + refg[k].numel()].view(shp) - refg[k].grad).abs().max().item()
+        assert e <= 3e-4 * max(refg[k].grad.abs().max().item(), 1e-9), (k, e)
+
+
+def test_c3_shape_f32_units_16_blocks_vs_oracle():
+    """BASELINE config C3's per-GPU shape: x4, 16 blocks / 32 units (fp32 parity mode, batch 2)"""
+    torch.manual_seed(12)
+    ns = _ns(num_blocks=16, num_residual_units=32)
+    m = _model(ns).train()
+    assert m.layout.total == 324528                         # SURVEY 8(a) a1
+    ref = O.OracleBasicModel(ns)
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()}, strict=True)
+    x = torch.rand(2, 3, 48, 48)
+    hr = torch.rand(2, 3, 192, 192)
+    y = m(x.cuda())
+    yr = ref(x)
+    assert (y.detach().cpu() - yr.detach()).abs().max().item() <= 3e-5 * yr.abs().max().item()
+    torch.nn.functional.l1_loss(y, hr.cuda()).backward()
+    torch.nn.functional.l1_loss(yr, hr).backward()
+    refg = dict(ref.named_parameters())
+    gflat = m.flat.grad.cpu()
+    worst = max(((gflat[off:off + refg[k].numel()].view(shp) - refg[k].grad).abs().max()
+                 / refg[k].grad.abs().max().clamp_min(1e-12)).item() for k, (off, shp) in m.layout.entries.items())
+    print(f"\nC3 shape worst rel grad err {worst:.2e}")
+    assert worst <= 5e-4
+
+
+def test_training_reduces_loss_bf16_and_matches_oracle_trajectory():
+    """10 Adam steps at C1 size: the bf16 hot path follows the fp32 oracle's loss curve (same init, same data)"""
+    torch.manual_seed(13)
+    ns = _ns(num_blocks=4, hot_dtype="bf16")
+    m = _model(ns).train()
+    ref = O.OracleBasicModel(ns)
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()}, strict=True)
+    x = torch.rand(4, 3, 24, 24)
+    hr = torch.nn.functional.interpolate(x, scale_factor=4, mode="bilinear")
+    o1 = torch.optim.Adam(m.parameters(), lr=1e-3)
+    o2 = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    l1, l2 = [], []
+    for _ in range(10):
+        o1.zero_grad(); o2.zero_grad()
+        a = torch.nn.functional.l1_loss(m(x.cuda()), hr.cuda()); a.backward(); o1.step(); l1.append(a.item())
+        b = torch.nn.functional.l1_loss(ref(x), hr); b.backward(); o2.step(); l2.append(b.item())
+    print("\nloss hot/bf16:", [round(v, 4) for v in l1], "\nloss oracle  :", [round(v, 4) for v in l2])
+    assert l1[-1] < 0.7 * l1[0]
+    assert all(abs(p - q) <= 0.05 * q + 2e-3 for p, q in zip(l1, l2))
+
+
+def test_linearity_of_backward_at_full_size():
+    """size-independent property at the BASELINE C2 shape: gradients are linear in the upstream gradient"""
+    torch.manual_seed(14)
+    m = _model(_ns(num_blocks=16, hot_dtype="fp32")).train()
+    x = torch.rand(32, 3, 48, 48, device="cuda")
+    g1 = torch.randn(32, 3, 192, 192, device="cuda")
+    g2 = torch.randn(32, 3, 192, 192, device="cuda")
+
+    def grad(g):
+        m.zero_grad(set_to_none=True)
+        m(x).backward(g)
+        return m.flat.grad.clone()
+    ga, gb, gc = grad(g1), grad(g2), grad(g1 + 2 * g2)
+    err = (gc - (ga + 2 * gb)).abs().max().item() / gc.abs().max().item()
+    print(f"\nlinearity rel err {err:.2e}")
+    assert err <= 2e-5
