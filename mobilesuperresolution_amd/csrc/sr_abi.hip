@@ -376,14 +376,18 @@ template <typename T> int net_pack(const sr_wdsr_net_t* n, hipStream_t st) {
   const int cb = (n->n_chan + 3) / 4, bb = (n->n_bias + 255) / 256;
   hipLaunchKernelGGL(wn_src_kernel, dim3(cb + bb), dim3(256), 0, st, n->flat, n->src, (const int4*)n->chan_tab,
                      n->n_chan, n->bias_tab, n->bias_const, n->n_bias, cb);
-  hipLaunchKernelGGL((pack_kernel<T>), dim3((n->n_idx_head + 255) / 256, 1), dim3(256), 0, st,
-                     n->src + n->src_head_off, n->idx_head, (T*)n->blob_head, n->n_idx_head, 0L);
-  hipLaunchKernelGGL((pack_kernel<T>), dim3(std::min((n->n_idx_body + 255) / 256, 64), n->NB), dim3(256), 0, st,
-                     n->src + n->src_body_off, n->idx_body, (T*)n->blob_body, n->n_idx_body, n->src_body_stride);
-  hipLaunchKernelGGL((pack_kernel<float>), dim3((n->n_idx_cinit + 255) / 256, n->NB), dim3(256), 0, st,
-                     n->src + n->src_body_off, n->idx_cinit, n->cinit_body, n->n_idx_cinit, n->src_body_stride);
-  hipLaunchKernelGGL((pack_kernel<T>), dim3(std::min((n->n_idx_tail + 255) / 256, 64), 1), dim3(256), 0, st,
-                     n->src + n->src_tail_off, n->idx_tail, (T*)n->blob_tail, n->n_idx_tail, 0L);
+  PackSegs ps;
+  ps.nseg = 4;
+  int blk = 0;
+  auto add = [&](int k, const int* idx, void* out, long off, long stride, int cnt, int reps, int as_float) {
+    ps.s[k] = PackSeg{idx, out, off, stride, cnt, reps, as_float, blk};
+    blk += reps * ((cnt + 255) / 256);
+  };
+  add(0, n->idx_head, n->blob_head, n->src_head_off, 0, n->n_idx_head, 1, 0);
+  add(1, n->idx_body, n->blob_body, n->src_body_off, n->src_body_stride, n->n_idx_body, n->NB, 0);
+  add(2, n->idx_cinit, n->cinit_body, n->src_body_off, n->src_body_stride, n->n_idx_cinit, n->NB, 1);
+  add(3, n->idx_tail, n->blob_tail, n->src_tail_off, 0, n->n_idx_tail, 1, 0);
+  hipLaunchKernelGGL((pack_all_kernel<T>), dim3(blk), dim3(256), 0, st, n->src, ps);
   SR_HIP_CHECK_LAUNCH();
   return 0;
 }
@@ -438,15 +442,21 @@ extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) 
   if ((rc = sr_head_wgrad(grads, n->x, n->mean, n->part_head, n->wgs_head, n->N, n->H, n->W, n->F, n->dtype, stream)))
     return rc;
   // slabs -> d(effective weights) -> d(flat parameters)
-  float* d_body = n->dsrc + n->src_body_off;
-  hipLaunchKernelGGL(unpack_sum_kernel, dim3(std::min((n->n_ga + 63) / 64, 64), n->NB), dim3(256), 0, st, n->part_a,
-                     n->wgs_body, (long)n->slab_a, n->ga_sidx, n->ga_dst, d_body, n->n_ga, n->src_body_stride);
-  hipLaunchKernelGGL(unpack_sum_kernel, dim3(std::min((n->n_gb + 63) / 64, 64), n->NB), dim3(256), 0, st, n->part_b,
-                     n->wgs_body, (long)n->slab_b, n->gb_sidx, n->gb_dst, d_body, n->n_gb, n->src_body_stride);
-  hipLaunchKernelGGL(unpack_sum_kernel, dim3((n->n_gt + 63) / 64, 1), dim3(256), 0, st, n->part_tail, n->wgs_tail,
-                     (long)n->slab_tail, n->gt_sidx, n->gt_dst, n->dsrc + n->src_tail_off, n->n_gt, 0L);
-  hipLaunchKernelGGL(unpack_sum_kernel, dim3((n->n_gh + 63) / 64, 1), dim3(256), 0, st, n->part_head, n->wgs_head,
-                     (long)n->slab_head, n->gh_sidx, n->gh_dst, n->dsrc + n->src_head_off, n->n_gh, 0L);
+  {
+    UnpackSegs us;
+    us.nseg = 4;
+    int blk = 0;
+    auto add = [&](int k, const float* part, const int* sidx, const int* dst, long off, long stride, long slab, int wgs,
+                   int cnt, int reps) {
+      us.s[k] = UnpackSeg{part, sidx, dst, off, stride, slab, wgs, cnt, reps, blk};
+      blk += reps * ((cnt + 63) / 64);
+    };
+    add(0, n->part_a, n->ga_sidx, n->ga_dst, n->src_body_off, n->src_body_stride, n->slab_a, n->wgs_body, n->n_ga, n->NB);
+    add(1, n->part_b, n->gb_sidx, n->gb_dst, n->src_body_off, n->src_body_stride, n->slab_b, n->wgs_body, n->n_gb, n->NB);
+    add(2, n->part_tail, n->gt_sidx, n->gt_dst, n->src_tail_off, 0, n->slab_tail, n->wgs_tail, n->n_gt, 1);
+    add(3, n->part_head, n->gh_sidx, n->gh_dst, n->src_head_off, 0, n->slab_head, n->wgs_head, n->n_gh, 1);
+    hipLaunchKernelGGL(unpack_all_kernel, dim3(blk), dim3(256), 0, st, n->dsrc, us);
+  }
   const int cb = (n->n_chan + 3) / 4, bb = (n->n_bias + 255) / 256;
   hipLaunchKernelGGL(wn_bwd_kernel, dim3(cb + bb), dim3(256), 0, st, n->flat, n->dsrc, n->gflat,
                      (const int4*)n->chan_tab, n->n_chan, n->bias_tab, n->n_bias, cb);

@@ -49,6 +49,25 @@ template <typename T, int S> SR_DEV typename FragOf<T>::type acc_to_frag(const f
   return f;
 }
 
+// relu(accumulator regs 8s..8s+7) as a fragment.  bf16: convert first, then a packed signed-integer max
+// with 0 on the bf16 bit patterns (sign-magnitude: negative <=> negative int16; -0 -> +0): half the VALU
+// ops of fmaxf on fp32, and none of the canonicalising v_max hipcc puts in front of fmaxf on MFMA output.
+template <typename T, int S> SR_DEV typename FragOf<T>::type acc_to_frag_relu(const f32x16& acc) {
+  if constexpr (sizeof(T) == 2) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const bf16x8 f = acc_to_frag<T, S>(acc);
+    s16x8 v = __builtin_bit_cast(s16x8, f);
+    const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    v = __builtin_elementwise_max(v, z);
+    return __builtin_bit_cast(bf16x8, v);
+  } else {
+    typename FragOf<T>::type f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = fmaxf(acc[8 * S + j], 0.f);
+    return f;
+  }
+}
+
 // accumulator regs 4g..4g+3 (rows 8g + 4hh + 0..3) -> 4 packed elements
 template <typename T> SR_DEV typename FragOf<T>::half_type acc_group(const f32x16& acc, int g) {
   typename FragOf<T>::half_type v;

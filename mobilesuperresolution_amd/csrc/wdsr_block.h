@@ -114,10 +114,8 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block_fw
       f32x16 hacc = C::FOLD_B1 ? zero16() : load_cinit(cinit + 32 + et * 32, hh);
 #pragma unroll
       for (int s = 0; s < C::KS1; ++s) hacc = mma16<T>(wsrc.get(C::W1_OFF + et * C::KS1 + s, lane), xb[s], hacc);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) hacc[i] = fmaxf(hacc[i], 0.f);
-      if (2 * et < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * et, lane), acc_to_frag<T, 0>(hacc), tacc);
-      if (2 * et + 1 < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * et + 1, lane), acc_to_frag<T, 1>(hacc), tacc);
+      if (2 * et < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * et, lane), acc_to_frag_relu<T, 0>(hacc), tacc);
+      if (2 * et + 1 < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * et + 1, lane), acc_to_frag_relu<T, 1>(hacc), tacc);
     }
     bool valid = false;
     if (hp < C::NPXH) {
@@ -425,10 +423,8 @@ SR_DEV f32x16 t_tile(const typename FragOf<T>::type (&xb)[C::KS1], const WS& wsr
     f32x16 hacc = C::FOLD_B1 ? zero16() : load_cinit(cinit + 32 + e2 * 32, hh);
 #pragma unroll
     for (int s = 0; s < C::KS1; ++s) hacc = mma16<T>(wsrc.get(C::W1_OFF + e2 * C::KS1 + s, lane), xb[s], hacc);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) hacc[i] = fmaxf(hacc[i], 0.f);
-    if (2 * e2 < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * e2, lane), acc_to_frag<T, 0>(hacc), tacc);
-    if (2 * e2 + 1 < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * e2 + 1, lane), acc_to_frag<T, 1>(hacc), tacc);
+    if (2 * e2 < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * e2, lane), acc_to_frag_relu<T, 0>(hacc), tacc);
+    if (2 * e2 + 1 < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * e2 + 1, lane), acc_to_frag_relu<T, 1>(hacc), tacc);
   }
   return tacc;
 }
@@ -600,14 +596,13 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           dh2[i] = h2[i] > 0.f ? dh2[i] : 0.f;
-          h2[i] = fmaxf(h2[i], 0.f);
           sum += dh2[i];
         }
         db1 += sum;
         accA = mma16<T>(tr_frag<T>(XC, 0, lane, rowx), acc_to_frag<T, 0>(dh2), accA);
         accA = mma16<T>(tr_frag<T>(XC, 1, lane, rowx), acc_to_frag<T, 1>(dh2), accA);
-        accB = mma16<T>(tr_frag<T>(IMG, 0, lane, rowi), acc_to_frag<T, 0>(h2), accB);
-        accB = mma16<T>(tr_frag<T>(IMG, 1, lane, rowi), acc_to_frag<T, 1>(h2), accB);
+        accB = mma16<T>(tr_frag<T>(IMG, 0, lane, rowi), acc_to_frag_relu<T, 0>(h2), accB);
+        accB = mma16<T>(tr_frag<T>(IMG, 1, lane, rowi), acc_to_frag_relu<T, 1>(h2), accB);
       }
     } else {
       const int uy = wave / 3, ux = wave - uy * 3;    // tap u = wave

@@ -102,3 +102,45 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ f
     if (b >= 0) gflat[b] = gval;
   }
 }
+
+// ---- fused forms: every packing / slab-gather segment of the network in ONE launch each ----
+struct PackSeg { const int* idx; void* out; long src_off, src_stride; int n, reps, as_float, block0; };
+struct PackSegs { PackSeg s[4]; int nseg; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__ src, PackSegs segs) {
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) if (i < segs.nseg && (int)blockIdx.x >= segs.s[i].block0) k = i;
+  const PackSeg sg = segs.s[k];
+  const int per_rep = (sg.n + 255) / 256;
+  const int b = blockIdx.x - sg.block0, rep = b / per_rep, i = (b - rep * per_rep) * 256 + threadIdx.x;
+  if (rep >= sg.reps || i >= sg.n) return;
+  const float v = src[sg.src_off + (size_t)rep * sg.src_stride + sg.idx[i]];
+  if (sg.as_float) reinterpret_cast<float*>(sg.out)[(size_t)rep * sg.n + i] = v;
+  else reinterpret_cast<T*>(sg.out)[(size_t)rep * sg.n + i] = (T)v;
+}
+
+struct UnpackSeg { const float* partial; const int* sidx; const int* dst; long dst_off, dst_stride, slab; int wgs, n, reps, block0; };
+struct UnpackSegs { UnpackSeg s[4]; int nseg; };
+
+__global__ __launch_bounds__(256) void unpack_all_kernel(float* __restrict__ dsrc, UnpackSegs segs) {
+  __shared__ float red[4][64];
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) if (i < segs.nseg && (int)blockIdx.x >= segs.s[i].block0) k = i;
+  const UnpackSeg sg = segs.s[k];
+  const int per_rep = (sg.n + 63) / 64;
+  const int b = blockIdx.x - sg.block0, rep = b / per_rep;
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6, i = (b - rep * per_rep) * 64 + e;
+  float acc = 0.f;
+  if (rep < sg.reps && i < sg.n) {
+    const float* p = sg.partial + (size_t)rep * sg.wgs * sg.slab + sg.sidx[i];
+#pragma unroll 4
+    for (int w = q; w < sg.wgs; w += 4) acc += p[(size_t)w * sg.slab];
+  }
+  red[q][e] = acc;
+  __syncthreads();
+  if (q == 0 && rep < sg.reps && i < sg.n)
+    dsrc[sg.dst_off + (size_t)rep * sg.dst_stride + sg.dst[i]] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+}
