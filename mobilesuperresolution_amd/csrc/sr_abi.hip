@@ -55,6 +55,19 @@ int launch_block_wgrad(const void* x, const void* dy, const void* wblob, const f
 
 }  // namespace
 
+extern "C" int sr_wdsr_block2_fwd(const void* x, void* ya, void* yb, const void* wa, const void* wb, const float* cia,
+                                  const float* cib, int N, int H, int W, int F, int dtype, sr_stream_t stream) {
+  if (!x || !ya || !yb || !wa || !wb || !cia || !cib || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
+  if (F != 24 || dtype != SR_DTYPE_BF16) return -1;
+  typedef BlockCfg<24, 144, 20> C;
+  const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
+  hipLaunchKernelGGL((wdsr_block2_fwd_kernel<__bf16, 24, 144, 20>), dim3(tiles_x * tiles_y, N),
+                     dim3(64 * Pair<24, 144, 20>::NWAVES), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)ya,
+                     (__bf16*)yb, (const __bf16*)wa, (const __bf16*)wb, cia, cib, H, W, tiles_x);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int sr_wdsr_block_fwd_stamps(const void* x, void* y, const void* wblob, const float* cinit, int N, int H,
                                         int W, int F, int dtype, unsigned long long* stamps, sr_stream_t stream) {
   if (F == 24 && dtype == SR_DTYPE_BF16)
@@ -404,7 +417,20 @@ extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int save_acts, sr_str
   char* acts = (char*)n->acts;
   if ((rc = sr_head_fwd(n->x, acts, n->blob_head, n->mean, n->N, n->H, n->W, n->F, n->dtype, stream))) return rc;
   char* cur = acts;
+  const bool pairs = save_acts && n->F == 24 && n->dtype == SR_DTYPE_BF16;   // two blocks per launch
   for (int i = 0; i < n->NB; ++i) {
+    if (pairs && i + 1 < n->NB) {
+      char* mid = acts + (size_t)(i + 1) * act;
+      char* nxt = acts + (size_t)(i + 2) * act;
+      if ((rc = sr_wdsr_block2_fwd(cur, mid, nxt, (char*)n->blob_body + i * blob, (char*)n->blob_body + (i + 1) * blob,
+                                   n->cinit_body + (size_t)i * n->n_idx_cinit,
+                                   n->cinit_body + (size_t)(i + 1) * n->n_idx_cinit, n->N, n->H, n->W, n->F, n->dtype,
+                                   stream)))
+        return rc;
+      cur = nxt;
+      ++i;
+      continue;
+    }
     char* nxt = save_acts ? acts + (size_t)(i + 1) * act : (cur == acts ? acts + act : acts);
     if ((rc = sr_wdsr_block_fwd(cur, nxt, (char*)n->blob_body + i * blob, n->cinit_body + (size_t)i * n->n_idx_cinit,
                                 n->N, n->H, n->W, n->F, n->dtype, stream)))

@@ -167,3 +167,24 @@ def test_block_bwd_bf16_tolerance(golden_dir, f):
         n = t.numel()
         cmp(name, dsrc[o:o + n], t.grad.reshape(-1))
         o += n
+
+
+@pytest.mark.parametrize("shape", [(3, 48, 48), (2, 20, 28), (1, 7, 9)])
+def test_block_pair_kernel_bit_identical_to_two_launches(shape):
+    """sr_wdsr_block2_fwd (two blocks per launch, halo-2 recompute) == two sr_wdsr_block_fwd launches, bit for bit"""
+    from mobilesuperresolution_amd import _lib as L, hotpath as HP
+    n, h, w = shape
+    f = 24
+    g = torch.Generator().manual_seed(21)
+    src = (torch.randn(2, HP.tables(f, torch.device("cuda", 0))["src_size"], generator=g) * 0.08).cuda()
+    src[:, -2], src[:, -1] = 0.0, 1.0
+    blob, cinit = HP.pack_blocks(src, f, torch.bfloat16)
+    x = torch.randn(n, h, w, f, generator=g).cuda().bfloat16()
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    HP.block_fwd(x, y1, blob[0], cinit[0])
+    HP.block_fwd(y1, y2, blob[1], cinit[1])
+    p1, p2 = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+    L.check(L.lib().sr_wdsr_block2_fwd(x.data_ptr(), p1.data_ptr(), p2.data_ptr(), blob[0].data_ptr(), blob[1].data_ptr(),
+                                       cinit[0].data_ptr(), cinit[1].data_ptr(), n, h, w, f, 1, L.stream_ptr()), "pair")
+    torch.cuda.synchronize()
+    assert torch.equal(p1, y1) and torch.equal(p2, y2)
