@@ -41,11 +41,18 @@ int sr_wdsr_block_fwd(const void* x, void* y, const void* wblob, const float* ci
                       int N, int H, int W, int F, int dtype, sr_stream_t stream);
 
 /* Two consecutive residual blocks in one launch (bf16, F = 24 only; -1 otherwise): x -> ya (block A's
- * output, kept because backward needs every block input) -> yb.  Bit-identical to two sr_wdsr_block_fwd
+ * output, kept because backward needs every block input; NULL = do not store) -> yb.  Bit-identical to two sr_wdsr_block_fwd
  * calls; exists because a single block launch at batch 32 is bound by its fixed costs. */
 int sr_wdsr_block2_fwd(const void* x, void* ya, void* yb, const void* wblob_a, const void* wblob_b,
                        const float* cinit_a, const float* cinit_b, int N, int H, int W, int F, int dtype,
                        sr_stream_t stream);
+
+/* Backward-data of two consecutive blocks in one launch (bf16, F = 24 only; -1 otherwise): block A feeds
+ * block B.  xa / xb = the blocks' inputs, dyb = gradient at B's output; writes dxb (= gradient at A's
+ * output, which the weight-gradient kernels read) and dxa.  Bit-identical to two sr_wdsr_block_bwd_data calls. */
+int sr_wdsr_block2_bwd_data(const void* xa, const void* xb, const void* dyb, void* dxb, void* dxa,
+                            const void* wblob_a, const void* wblob_b, const float* cinit_a, const float* cinit_b,
+                            int N, int H, int W, int F, int dtype, sr_stream_t stream);
 
 /* Measurement aid for bench.py's roofline leg: `reps` back-to-back launches of the same forward kernel,
  * ping-ponging x <-> y, so that HIP events around the call measure the kernel and not the host. */

@@ -57,7 +57,7 @@ int launch_block_wgrad(const void* x, const void* dy, const void* wblob, const f
 
 extern "C" int sr_wdsr_block2_fwd(const void* x, void* ya, void* yb, const void* wa, const void* wb, const float* cia,
                                   const float* cib, int N, int H, int W, int F, int dtype, sr_stream_t stream) {
-  if (!x || !ya || !yb || !wa || !wb || !cia || !cib || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
+  if (!x || !yb || !wa || !wb || !cia || !cib || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
   if (F != 24 || dtype != SR_DTYPE_BF16) return -1;
   typedef BlockCfg<24, 144, 20> C;
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
@@ -97,6 +97,22 @@ extern "C" int sr_wdsr_block_bwd_data(const void* x, const void* dy, void* dx, c
   if (F == 32 && dtype == SR_DTYPE_BF16) return launch_block_bwd_data<__bf16, 32, 192, 26>(x, dy, dx, wblob, cinit, N, H, W, st);
   if (F == 32 && dtype == SR_DTYPE_F32) return launch_block_bwd_data<float, 32, 192, 26>(x, dy, dx, wblob, cinit, N, H, W, st);
   return -1;
+}
+
+extern "C" int sr_wdsr_block2_bwd_data(const void* xa, const void* xb, const void* dyb, void* dxb, void* dxa,
+                                       const void* wa, const void* wb, const float* cia, const float* cib, int N,
+                                       int H, int W, int F, int dtype, sr_stream_t stream) {
+  if (!xa || !xb || !dyb || !dxb || !dxa || !wa || !wb || !cia || !cib || N <= 0 || H <= 0 || W <= 0 || N > 65535)
+    return -2;
+  if (F != 24 || dtype != SR_DTYPE_BF16) return -1;
+  typedef BlockCfg<24, 144, 20> C;
+  const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
+  hipLaunchKernelGGL((wdsr_block2_bwd_data_kernel<__bf16, 24, 144, 20>), dim3(tiles_x * tiles_y, N),
+                     dim3(64 * C::NPT_H), 0, (hipStream_t)stream, (const __bf16*)xa, (const __bf16*)xb,
+                     (const __bf16*)dyb, (__bf16*)dxb, (__bf16*)dxa, (const __bf16*)wa, (const __bf16*)wb, cia, cib, H,
+                     W, tiles_x);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int sr_wdsr_block_wgrad(const void* x, const void* dy, const void* wblob, const float* cinit,
@@ -417,11 +433,11 @@ extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int save_acts, sr_str
   char* acts = (char*)n->acts;
   if ((rc = sr_head_fwd(n->x, acts, n->blob_head, n->mean, n->N, n->H, n->W, n->F, n->dtype, stream))) return rc;
   char* cur = acts;
-  const bool pairs = save_acts && n->F == 24 && n->dtype == SR_DTYPE_BF16;   // two blocks per launch
+  const bool pairs = n->F == 24 && n->dtype == SR_DTYPE_BF16;   // two blocks per launch
   for (int i = 0; i < n->NB; ++i) {
     if (pairs && i + 1 < n->NB) {
-      char* mid = acts + (size_t)(i + 1) * act;
-      char* nxt = acts + (size_t)(i + 2) * act;
+      char* mid = save_acts ? acts + (size_t)(i + 1) * act : nullptr;   // inference keeps nothing
+      char* nxt = save_acts ? acts + (size_t)(i + 2) * act : (cur == acts ? acts + act : acts);
       if ((rc = sr_wdsr_block2_fwd(cur, mid, nxt, (char*)n->blob_body + i * blob, (char*)n->blob_body + (i + 1) * blob,
                                    n->cinit_body + (size_t)i * n->n_idx_cinit,
                                    n->cinit_body + (size_t)(i + 1) * n->n_idx_cinit, n->N, n->H, n->W, n->F, n->dtype,
@@ -456,11 +472,24 @@ extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) 
   if ((rc = sr_tail_wgrad(n->dout, acts + (size_t)n->NB * act, n->x, n->mean, n->part_tail, n->wgs_tail, n->N, n->H,
                           n->W, n->F, n->R, n->dtype, stream)))
     return rc;
-  for (int i = n->NB - 1; i >= 0; --i)
+  const bool pairs = n->F == 24 && n->dtype == SR_DTYPE_BF16;   // two blocks per launch
+  for (int i = n->NB - 1; i >= 0; --i) {
+    if (pairs && i >= 1) {
+      if ((rc = sr_wdsr_block2_bwd_data(acts + (size_t)(i - 1) * act, acts + (size_t)i * act, grads + (size_t)(i + 1) * act,
+                                        grads + (size_t)i * act, grads + (size_t)(i - 1) * act,
+                                        (char*)n->blob_body + (i - 1) * blob, (char*)n->blob_body + i * blob,
+                                        n->cinit_body + (size_t)(i - 1) * n->n_idx_cinit,
+                                        n->cinit_body + (size_t)i * n->n_idx_cinit, n->N, n->H, n->W, n->F, n->dtype,
+                                        stream)))
+        return rc;
+      --i;
+      continue;
+    }
     if ((rc = sr_wdsr_block_bwd_data(acts + (size_t)i * act, grads + (size_t)(i + 1) * act, grads + (size_t)i * act,
                                      (char*)n->blob_body + i * blob, n->cinit_body + (size_t)i * n->n_idx_cinit, n->N,
                                      n->H, n->W, n->F, n->dtype, stream)))
       return rc;
+  }
   if ((rc = sr_wdsr_block_wgrad(acts, grads + act, n->blob_body, n->cinit_body, n->part_a, n->part_b, n->NB,
                                 n->wgs_body, n->N, n->H, n->W, n->F, n->dtype, act_e, act_e, (long)n->n_idx_body,
                                 (long)n->n_idx_cinit, stream)))

@@ -828,7 +828,7 @@ __global__ __launch_bounds__((64 * Pair<F, E, L>::NWAVES)) void wdsr_block2_fwd_
 #pragma unroll
       for (int g = 0; g < C::FC; ++g) *reinterpret_cast<HalfT*>(XB + hp1 * C::KX + g * 8 + hh * 4) = acc_group<T>(oacc, g);
       const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
-      if (hy >= 1 && hy <= C::TH && hx >= 1 && hx <= C::TW && Y < H && X < W) {
+      if (ya && hy >= 1 && hy <= C::TH && hx >= 1 && hx <= C::TW && Y < H && X < W) {
         T* o = ya + img + ((size_t)Y * W + X) * F;
 #pragma unroll
         for (int g = 0; g < C::FC; ++g) *reinterpret_cast<HalfT*>(o + g * 8 + hh * 4) = acc_group<T>(oacc, g);
@@ -869,6 +869,196 @@ __global__ __launch_bounds__((64 * Pair<F, E, L>::NWAVES)) void wdsr_block2_fwd_
       T* o = yb + img + ((size_t)Y * W + X) * F;
 #pragma unroll
       for (int g = 0; g < C::FC; ++g) *reinterpret_cast<HalfT*>(o + g * 8 + hh * 4) = acc_group<T>(oacc, g);
+    }
+  }
+}
+
+// =============================================================================================
+// backward-data of two consecutive blocks per launch (bf16, F = 24; same reasoning as the forward pair):
+// dyB (gradient at block B's output) -> dxB = dyA on the tile + 1-pixel halo (LDS, and HBM for the core:
+// the weight-gradient kernels read it) -> dxA on the core.  Bit-identical to two single-block launches.
+//   phase 1 (12 waves): dxB on the 14x26 region from dyB on the 16x28 region and xB (= block A's output)
+//   phase 2 ( 9 waves): dxA on the 12x24 core from the LDS dxB image and xA
+// =============================================================================================
+template <typename T, int NTHREADS, int RW, int NROWS, int NLIVE, int CH, int FCH, bool ONES> struct RegionRegs {
+  typedef typename FragOf<T>::type FragT;
+  static constexpr int TOTAL = NROWS * CH, ITER = (TOTAL + NTHREADS - 1) / NTHREADS;
+  FragT v[ITER];
+  // rows p < NLIVE are pixels (y0 + p / RW, x0 + p % RW) of the NHWC image `src` (FCH chunks of 8 channels);
+  // everything else, and pixels outside the image, is zero; chunk FCH carries the ones channel if ONES
+  SR_DEV void load(const T* __restrict__ src, int H, int W, int y0, int x0, int tid) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + it * NTHREADS;
+      const int p = idx / CH, c = idx - p * CH;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[it][j] = (T)0.f;
+      if (idx < TOTAL) {
+        if (c < FCH) {
+          if (p < NLIVE) {
+            const int py = p / RW, px = p - py * RW;
+            const int Y = y0 + py, X = x0 + px;
+            if (Y >= 0 && Y < H && X >= 0 && X < W) v[it] = *reinterpret_cast<const FragT*>(src + ((size_t)Y * W + X) * (FCH * 8) + c * 8);
+          }
+        } else if (ONES && c == FCH) {
+          v[it][0] = (T)1.f;
+        }
+      }
+    }
+  }
+  SR_DEV void store(T* dst, int tid) const {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + it * NTHREADS;
+      if (idx < TOTAL) *reinterpret_cast<FragT*>(dst + idx * 8) = v[it];
+    }
+  }
+};
+
+// dx^T for 32 pixels: dy + W1^T [ 1(h>0) * W2^T dt ], h recomputed from the x row; `dyoff` = element offset
+// of each lane's own pixel in the dy image (identity term)
+template <typename T, typename C, typename WS>
+SR_DEV f32x16 dx_from_dt(const f32x16& dtacc, const T* Ximg, int xrow, const T* DYimg, int dyoff, const WS& wsrc,
+                         int lw2t, int lw1t, int lid, const float* __restrict__ cinit, int lane) {
+  typedef BwdCfg<C> B;
+  typedef typename FragOf<T>::type FragT;
+  const int hh = lane >> 5;
+  const FragT dtb0 = acc_to_frag<T, 0>(dtacc), dtb1 = acc_to_frag<T, 1>(dtacc);
+  FragT xb[C::KS1];
+#pragma unroll
+  for (int s = 0; s < C::KS1; ++s) xb[s] = lds_chunk<T>(Ximg, xrow * C::KX + (2 * s + hh) * 8);
+  f32x16 dxacc = zero16();
+#pragma unroll
+  for (int et = 0; et < C::NET; ++et) {
+    f32x16 hacc = C::FOLD_B1 ? zero16() : load_cinit(cinit + 32 + et * 32, hh);
+#pragma unroll
+    for (int s = 0; s < C::KS1; ++s) hacc = mma16<T>(wsrc.get(C::W1_OFF + et * C::KS1 + s, lane), xb[s], hacc);
+    f32x16 dh = zero16();
+    dh = mma16<T>(wsrc.get(lw2t + 2 * et, lane), dtb0, dh);
+    dh = mma16<T>(wsrc.get(lw2t + 2 * et + 1, lane), dtb1, dh);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dh[i] = hacc[i] > 0.f ? dh[i] : 0.f;
+    if (2 * et < C::KS2) dxacc = mma16<T>(wsrc.get(lw1t + 2 * et, lane), acc_to_frag<T, 0>(dh), dxacc);
+    if (2 * et + 1 < C::KS2) dxacc = mma16<T>(wsrc.get(lw1t + 2 * et + 1, lane), acc_to_frag<T, 1>(dh), dxacc);
+  }
+#pragma unroll
+  for (int s = 0; s < B::KSI; ++s) {
+    int c = 2 * s + hh;
+    if (c >= C::FC) c = 0;
+    dxacc = mma16<T>(wsrc.get(lid + s, lane), lds_chunk<T>(DYimg, dyoff + c * 8), dxacc);
+  }
+  return dxacc;
+}
+
+// dt^T for 32 pixels, taps at DY[(hbase + ty * stride + tx)]
+template <typename T, typename C, typename WS>
+SR_DEV f32x16 dt_from_dy(const T* DYs, int hbase, int stride, const WS& wsrc, int w3t_base, int lane) {
+  typedef BwdCfg<C> B;
+  const int hh = lane >> 5;
+  f32x16 acc = zero16();
+#pragma unroll
+  for (int s = 0; s < B::KS3B; ++s) {
+    const int q = 2 * s + hh;
+    int off = hbase * C::F;
+    if (q < 9 * C::FC) {
+      const int u = q / C::FC, c = q - u * C::FC;
+      off = (hbase + (u / 3) * stride + (u % 3)) * C::F + c * 8;
+    }
+    acc = mma16<T>(wsrc.get(w3t_base + s, lane), lds_chunk<T>(DYs, off), acc);
+  }
+  return acc;
+}
+
+template <typename T, int F, int E, int L>
+__global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block2_bwd_data_kernel(
+    const T* __restrict__ xa, const T* __restrict__ xb, const T* __restrict__ dyb, T* __restrict__ dxb,
+    T* __restrict__ dxa, const T* __restrict__ wa, const T* __restrict__ wb, const float* __restrict__ cia,
+    const float* __restrict__ cib, int H, int W, int tiles_x) {
+  typedef BlockCfg<F, E, L> C;
+  typedef BwdCfg<C> B;
+  typedef Pair<F, E, L> P;
+  typedef typename FragOf<T>::half_type HalfT;
+  constexpr int NTHREADS = 64 * C::NPT_H;
+  constexpr int NW1 = C::NET * C::KS1, NREST = B::W2N_OFF - B::W3T_OFF, NWL = NW1 + NREST;
+  constexpr int LW3T = NW1, LW2T = LW3T + B::KS3B, LW1T = LW2T + 2 * C::NET, LID = LW1T + C::KS2;
+  constexpr int DY2_ELEMS = (P::NP2 + 2) * C::F, XB_ELEMS = C::NPXH_PAD * C::KX;
+  static_assert(B::XC_ELEMS <= DY2_ELEMS, "xA reuses the dyB image");
+  __shared__ __attribute__((aligned(16))) T smem[DY2_ELEMS + XB_ELEMS + B::DY_ELEMS + 2 * NWL * 512];
+  T* const DY2 = smem;
+  T* const XBs = DY2 + DY2_ELEMS;
+  T* const DY1 = XBs + XB_ELEMS;
+  T* const XA = DY2;                      // phase 2 only: xA waits in registers during phase 1 (LDS budget)
+  T* const WL = DY1 + B::DY_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+  const size_t img = (size_t)n * H * W * F;
+
+  WSrc<T, true> wsa, wsb;
+  wsa.p = WL;
+  wsb.p = WL + NWL * 512;
+  stage_weights<T, NTHREADS>(WL, wa, NW1, tid);
+  stage_weights<T, NTHREADS>(WL + NW1 * 512, wa + (size_t)B::W3T_OFF * 512, NREST, tid);
+  stage_weights<T, NTHREADS>(WL + NWL * 512, wb, NW1, tid);
+  stage_weights<T, NTHREADS>(WL + (NWL + NW1) * 512, wb + (size_t)B::W3T_OFF * 512, NREST, tid);
+  RegionRegs<T, NTHREADS, C::TW, B::NPXC + 1, B::NPXC, C::KX / 8, C::FC, C::FOLD_B1> ra;
+  {
+    RegionRegs<T, NTHREADS, P::W2, P::NP2 + 2, P::NP2, C::FC, C::FC, false> rd;
+    RegionRegs<T, NTHREADS, C::HW, C::NPXH_PAD, C::NPXH, C::KX / 8, C::FC, C::FOLD_B1> rb;
+    rd.load(dyb + img, H, W, ty0 - 2, tx0 - 2, tid);
+    rb.load(xb + img, H, W, ty0 - 1, tx0 - 1, tid);
+    ra.load(xa + img, H, W, ty0, tx0, tid);
+    rd.store(DY2, tid);
+    rb.store(XBs, tid);
+    // slack rows of the dxB image (read by the padded taps of phase 2, never written by phase 1)
+    for (int i = tid; i < (C::NPXH_PAD + 2 - C::NPXH) * C::F; i += NTHREADS) DY1[C::NPXH * C::F + i] = (T)0.f;
+  }
+  __syncthreads();
+
+  // ---- phase 1: dxB on the 14x26 region ----
+  {
+    const int hp1 = wave * 32 + r;
+    const bool live = hp1 < C::NPXH;
+    const int hp1c = live ? hp1 : 0;
+    const int hy = hp1c / C::HW, hx = hp1c - hy * C::HW;
+    const f32x16 dtacc = dt_from_dy<T, C>(DY2, hy * P::W2 + hx, P::W2, wsb, LW3T, lane);
+    const f32x16 dxacc = dx_from_dt<T, C>(dtacc, XBs, hp1c, DY2, ((hy + 1) * P::W2 + hx + 1) * C::F, wsb, LW2T, LW1T,
+                                           LID, cib, lane);
+    if (live) {
+      const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
+      const bool inimg = (Y >= 0 && Y < H && X >= 0 && X < W);
+#pragma unroll
+      for (int g = 0; g < C::FC; ++g) {
+        HalfT v = acc_group<T>(dxacc, g);
+        if (!inimg) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (T)0.f;
+        }
+        *reinterpret_cast<HalfT*>(DY1 + hp1 * C::F + g * 8 + hh * 4) = v;
+      }
+      if (inimg && hy >= 1 && hy <= C::TH && hx >= 1 && hx <= C::TW) {
+        T* o = dxb + img + ((size_t)Y * W + X) * F;
+#pragma unroll
+        for (int g = 0; g < C::FC; ++g) *reinterpret_cast<HalfT*>(o + g * 8 + hh * 4) = acc_group<T>(dxacc, g);
+      }
+    }
+  }
+  __syncthreads();
+  ra.store(XA, tid);
+  __syncthreads();
+
+  // ---- phase 2: dxA on the core ----
+  if (wave < C::NPT_O) {
+    const int ot = wave;
+    const int oy = (ot / (C::TW / 8)) * 4 + (r >> 3), ox = (ot % (C::TW / 8)) * 8 + (r & 7);
+    const int hbase = oy * C::HW + ox, pc = oy * C::TW + ox;
+    const f32x16 dtacc = dt_from_dy<T, C>(DY1, hbase, C::HW, wsa, LW3T, lane);
+    const f32x16 dxacc = dx_from_dt<T, C>(dtacc, XA, pc, DY1, (hbase + C::HW + 1) * C::F, wsa, LW2T, LW1T, LID, cia, lane);
+    const int Y = ty0 + oy, X = tx0 + ox;
+    if (Y < H && X < W) {
+      T* o = dxa + img + ((size_t)Y * W + X) * F;
+#pragma unroll
+      for (int g = 0; g < C::FC; ++g) *reinterpret_cast<HalfT*>(o + g * 8 + hh * 4) = acc_group<T>(dxacc, g);
     }
   }
 }

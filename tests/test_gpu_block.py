@@ -188,3 +188,27 @@ def test_block_pair_kernel_bit_identical_to_two_launches(shape):
                                        cinit[0].data_ptr(), cinit[1].data_ptr(), n, h, w, f, 1, L.stream_ptr()), "pair")
     torch.cuda.synchronize()
     assert torch.equal(p1, y1) and torch.equal(p2, y2)
+
+
+@pytest.mark.parametrize("shape", [(3, 48, 48), (2, 20, 28), (1, 7, 9)])
+def test_block_pair_bwd_data_bit_identical_to_two_launches(shape):
+    """sr_wdsr_block2_bwd_data == two sr_wdsr_block_bwd_data launches, bit for bit (incl. ragged tiles)"""
+    from mobilesuperresolution_amd import _lib as L, hotpath as HP
+    n, h, w = shape
+    f = 24
+    g = torch.Generator().manual_seed(22)
+    src = (torch.randn(2, HP.tables(f, torch.device("cuda", 0))["src_size"], generator=g) * 0.08).cuda()
+    src[:, -2], src[:, -1] = 0.0, 1.0
+    blob, cinit = HP.pack_blocks(src, f, torch.bfloat16)
+    xa = torch.randn(n, h, w, f, generator=g).cuda().bfloat16()
+    xb = torch.randn(n, h, w, f, generator=g).cuda().bfloat16()
+    dyb = torch.randn(n, h, w, f, generator=g).cuda().bfloat16()
+    d1, d0 = torch.empty_like(xa), torch.empty_like(xa)
+    HP.block_bwd_data(xb, dyb, d1, blob[1], cinit[1])
+    HP.block_bwd_data(xa, d1, d0, blob[0], cinit[0])
+    p1, p0 = torch.full_like(xa, float("nan")), torch.full_like(xa, float("nan"))
+    L.check(L.lib().sr_wdsr_block2_bwd_data(xa.data_ptr(), xb.data_ptr(), dyb.data_ptr(), p1.data_ptr(), p0.data_ptr(),
+                                            blob[0].data_ptr(), blob[1].data_ptr(), cinit[0].data_ptr(), cinit[1].data_ptr(),
+                                            n, h, w, f, 1, L.stream_ptr()), "pair bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(p1, d1) and torch.equal(p0, d0)
