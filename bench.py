@@ -180,22 +180,35 @@ def main():
         st = model._state(dev)
         tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
         a = torch.randn(BATCH, LR, LR, UNITS, device=dev).to(tdt)
-        b = torch.empty_like(a)
+        b, c = torch.empty_like(a), torch.empty_like(a)
         reps = 320
+        blob, cin = st.blob_body, st.cinit_body
+        pair = args.dtype == "bf16" and UNITS == 24          # the two-block kernel is what the step launches
 
-        def chain():
+        def chain1():
             L.launch("sr_wdsr_block_fwd_repeat", L.lib().sr_wdsr_block_fwd_repeat, a.data_ptr(), b.data_ptr(),
-                     st.blob_body[BLOCKS - 1].data_ptr(), st.cinit_body[BLOCKS - 1].data_ptr(), BATCH, LR, LR, UNITS,
+                     blob[BLOCKS - 1].data_ptr(), cin[BLOCKS - 1].data_ptr(), BATCH, LR, LR, UNITS,
                      L.DTYPE_CODE[tdt], reps, L.stream_ptr())
-        chain()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        chain()
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / reps
-        achieved = alg["sr_wdsr_block_fwd"] / (us * 1e-6) / 1e9
+
+        def chain2():
+            L.launch("sr_wdsr_block2_fwd_repeat", L.lib().sr_wdsr_block2_fwd_repeat, a.data_ptr(), b.data_ptr(),
+                     c.data_ptr(), blob[BLOCKS - 2].data_ptr(), blob[BLOCKS - 1].data_ptr(), cin[BLOCKS - 2].data_ptr(),
+                     cin[BLOCKS - 1].data_ptr(), BATCH, LR, LR, UNITS, L.DTYPE_CODE[tdt], reps, L.stream_ptr())
+
+        def timed(chain):
+            chain()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()                                       # torch's current stream == the launch stream
+            chain()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / reps
+        us1 = timed(chain1)
+        us = timed(chain2) if pair else us1
+        units = 2 if pair else 1                              # residual blocks per launch
+        alg_launch = units * alg["sr_wdsr_block_fwd"]
+        achieved = alg_launch / (us * 1e-6) / 1e9
         # whole forward / backward calls, for the record
         timer = L.KernelTimer()
         L.set_timer(timer)
@@ -204,15 +217,19 @@ def main():
         L.set_timer(None)
         calls = {k: round(v[1] * 1e3, 1) for k, v in timer.summary().items()}
         traffic = None                                   # PMC bytes per launch, collected offline with rocprofv3 --pmc
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_block_fwd.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_block2_fwd.json" if pair else "r01_pmc_block_fwd.json")
         if args.dtype == "bf16" and os.path.exists(pmc):
             traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
-        roofline = {"kernel": f"wdsr_block_fwd_kernel<{args.dtype},24,144,20>", "bound": "hbm",
+        kname = "wdsr_block2_fwd_kernel" if pair else "wdsr_block_fwd_kernel"
+        roofline = {"kernel": f"{kname}<{args.dtype},24,144,20>", "bound": "hbm",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "alg_bytes_per_launch": alg["sr_wdsr_block_fwd"], "avg_launch_us": round(us, 2),
+                    "alg_bytes_per_launch": alg_launch, "blocks_per_launch": units, "avg_launch_us": round(us, 2),
+                    "single_block_kernel": {"avg_launch_us": round(us1, 2),
+                                            "achieved": round(alg["sr_wdsr_block_fwd"] / (us1 * 1e-6) / 1e9, 1)},
                     "how": f"{reps} back-to-back launches from one C call, HIP events on the launch stream "
-                           "(includes inter-launch gaps)"}
+                           "(includes inter-launch gaps); algorithmic bytes = SURVEY 8(d) per-block figure "
+                           "(read x + write y) x blocks per launch"}
         kernels = {"call_us": calls}
         out = {
             "metric": "HR megapixels/sec (WDSR-B x4, 48x48 LR patches), full training step",

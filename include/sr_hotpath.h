@@ -58,6 +58,10 @@ int sr_wdsr_block2_bwd_data(const void* xa, const void* xb, const void* dyb, voi
  * ping-ponging x <-> y, so that HIP events around the call measure the kernel and not the host. */
 int sr_wdsr_block_fwd_repeat(void* x, void* y, const void* wblob, const float* cinit,
                              int N, int H, int W, int F, int dtype, int reps, sr_stream_t stream);
+/* Same for the two-block kernel: launch i reads x (even i) or yb (odd i), writes ya and the other one. */
+int sr_wdsr_block2_fwd_repeat(void* x, void* ya, void* yb, const void* wblob_a, const void* wblob_b,
+                              const float* cinit_a, const float* cinit_b, int N, int H, int W, int F, int dtype,
+                              int reps, sr_stream_t stream);
 
 /* Diagnostic: one forward launch (bf16) that also records, per workgroup, 6 s_memrealtime stamps (100 MHz):
  * start, x/weights staged, after barrier, phase A done, after barrier, end -> stamps[wg][8]. */

@@ -20,6 +20,7 @@ SIGNATURES = {
     "sr_wdsr_block_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block2_fwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block2_bwd_data": ([_P] * 9 + [_I] * 5 + [_P], _I),
+    "sr_wdsr_block2_fwd_repeat": ([_P] * 7 + [_I] * 6 + [_P], _I),
     "sr_wdsr_block_fwd_stamps": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P], _I),
     "sr_wdsr_block_fwd_repeat": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block_bwd_data": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),

@@ -87,6 +87,17 @@ extern "C" int sr_wdsr_block_fwd_repeat(void* x, void* y, const void* wblob, con
   return 0;
 }
 
+extern "C" int sr_wdsr_block2_fwd_repeat(void* x, void* ya, void* yb, const void* wa, const void* wb, const float* cia,
+                                         const float* cib, int N, int H, int W, int F, int dtype, int reps,
+                                         sr_stream_t stream) {
+  for (int i = 0; i < reps; ++i) {
+    const int rc = (i & 1) ? sr_wdsr_block2_fwd(yb, ya, x, wa, wb, cia, cib, N, H, W, F, dtype, stream)
+                           : sr_wdsr_block2_fwd(x, ya, yb, wa, wb, cia, cib, N, H, W, F, dtype, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 extern "C" int sr_wdsr_block_bwd_data(const void* x, const void* dy, void* dx, const void* wblob,
                                       const float* cinit, int N, int H, int W, int F, int dtype,
                                       sr_stream_t stream) {
