@@ -44,15 +44,27 @@ int sr_wdsr_block_fwd(const void* x, void* y, const void* wblob, const float* ci
  * output, kept because backward needs every block input; NULL = do not store) -> yb.  Bit-identical to two sr_wdsr_block_fwd
  * calls; exists because a single block launch at batch 32 is bound by its fixed costs. */
 int sr_wdsr_block2_fwd(const void* x, void* ya, void* yb, const void* wblob_a, const void* wblob_b,
-                       const float* cinit_a, const float* cinit_b, int N, int H, int W, int F, int dtype,
-                       sr_stream_t stream);
+                       const float* cinit_a, const float* cinit_b, void* tsave_a, void* tsave_b, int N, int H, int W,
+                       int F, int dtype, sr_stream_t stream);
+/* tsave_a / tsave_b (NULL = off): keep each block's t = conv1x1(relu(conv1x1(x))) (the 3x3 conv's input,
+ * basic_wdsr_b.py:131-137) for the core pixels, tile-local [N][tiles][288][24] bf16, for
+ * sr_wdsr_block_wgrad_saved. */
 
 /* Backward-data of two consecutive blocks in one launch (bf16, F = 24 only; -1 otherwise): block A feeds
  * block B.  xa / xb = the blocks' inputs, dyb = gradient at B's output; writes dxb (= gradient at A's
  * output, which the weight-gradient kernels read) and dxa.  Bit-identical to two sr_wdsr_block_bwd_data calls. */
 int sr_wdsr_block2_bwd_data(const void* xa, const void* xb, const void* dyb, void* dxb, void* dxa,
                             const void* wblob_a, const void* wblob_b, const float* cinit_a, const float* cinit_b,
-                            int N, int H, int W, int F, int dtype, sr_stream_t stream);
+                            void* dtsave_a, void* dtsave_b, int N, int H, int W, int F, int dtype, sr_stream_t stream);
+/* dtsave_a / dtsave_b (NULL = off): keep each block's dt = conv3x3^T(dy), same layout as tsave.
+ *
+ * Weight gradients of `layers` blocks from the saved t / dt images instead of recomputing them (bf16,
+ * F = 24 only; -1 otherwise).  Same slabs as sr_wdsr_block_wgrad.  side_ls = elements between two blocks'
+ * saved images. */
+int sr_wdsr_block_wgrad_saved(const void* x, const void* dy, const void* tsave, const void* dtsave,
+                              const void* wblob, float* partial_a, float* partial_b, int layers, int wgs, int N,
+                              int H, int W, int F, int dtype, long x_ls, long dy_ls, long side_ls, long w_ls,
+                              sr_stream_t stream);
 
 /* Measurement aid for bench.py's roofline leg: `reps` back-to-back launches of the same forward kernel,
  * ping-ponging x <-> y, so that HIP events around the call measure the kernel and not the host. */
@@ -184,6 +196,8 @@ typedef struct {
   /* activations: x NCHW fp32; acts/grads [(NB+1)][N][H][W][F] (acts may be 2 ping-pong slots when
    * save_acts == 0); out / dout NCHW fp32 [N][3][R*H][R*W] */
   const float* x; void* acts; void* grads; float* out; const float* dout;
+  /* optional (bf16, F = 24, even NB; NULL = recompute in backward): t and dt of every block, [NB][N][tiles][288][24] */
+  void* tsave; void* dtsave;
 } sr_wdsr_net_t;
 
 /* weight-norm + packing + head + NB fused blocks + fused tail.  save_acts != 0 keeps every block input
@@ -199,6 +213,12 @@ int sr_probe_tr_read(const void* img_bf16, int n_elems, const int* lane_elem_off
                      sr_stream_t stream);
 /* streaming copy of n_bytes (multiple of 16): the achievable-HBM-bandwidth yardstick for bench.py */
 int sr_probe_copy(const void* src, void* dst, size_t n_bytes, sr_stream_t stream);
+/* Launch-floor probe: `reps` dependent launches of an empty kernel with the given grid, workgroup size and
+ * dynamic LDS; writes gx*gy words to `out`.  Timing it gives the fixed cost under every chained kernel. */
+int sr_probe_launch_floor(void* out, int gx, int gy, int threads, int lds_bytes, int reps, sr_stream_t stream);
+/* The same chain captured in a hipGraph and replayed `iters` times (synchronous; result in *us_per_launch). */
+int sr_probe_launch_floor_graph(void* out, int gx, int gy, int threads, int lds_bytes, int reps, int iters,
+                                float* us_per_launch);
 
 #ifdef __cplusplus
 }

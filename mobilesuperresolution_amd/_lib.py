@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsr_hotpath.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
 
 _P, _I, _Z, _L, _F = c_void_p, c_int, c_size_t, ctypes.c_long, ctypes.c_float
@@ -18,9 +18,12 @@ _P, _I, _Z, _L, _F = c_void_p, c_int, c_size_t, ctypes.c_long, ctypes.c_float
 SIGNATURES = {
     "sr_abi_version": ([], _I),
     "sr_wdsr_block_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
-    "sr_wdsr_block2_fwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
-    "sr_wdsr_block2_bwd_data": ([_P] * 9 + [_I] * 5 + [_P], _I),
+    "sr_wdsr_block2_fwd": ([_P] * 9 + [_I] * 5 + [_P], _I),
+    "sr_wdsr_block_wgrad_saved": ([_P] * 7 + [_I] * 7 + [_L] * 4 + [_P], _I),
+    "sr_wdsr_block2_bwd_data": ([_P] * 11 + [_I] * 5 + [_P], _I),
     "sr_wdsr_block2_fwd_repeat": ([_P] * 7 + [_I] * 6 + [_P], _I),
+    "sr_probe_launch_floor": ([_P, _I, _I, _I, _I, _I, _P], _I),
+    "sr_probe_launch_floor_graph": ([_P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block_fwd_stamps": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P], _I),
     "sr_wdsr_block_fwd_repeat": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block_bwd_data": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
@@ -63,7 +66,7 @@ class WdsrNet(ctypes.Structure):
         [(n, _I) for n in ("wgs_body", "wgs_tail", "wgs_head", "slab_a", "slab_b", "slab_tail", "slab_head")] +
         [("ga_sidx", _P), ("ga_dst", _P), ("n_ga", _I), ("gb_sidx", _P), ("gb_dst", _P), ("n_gb", _I),
          ("gt_sidx", _P), ("gt_dst", _P), ("n_gt", _I), ("gh_sidx", _P), ("gh_dst", _P), ("n_gh", _I),
-         ("x", _P), ("acts", _P), ("grads", _P), ("out", _P), ("dout", _P)])
+         ("x", _P), ("acts", _P), ("grads", _P), ("out", _P), ("dout", _P), ("tsave", _P), ("dtsave", _P)])
 
 
 _lib = None

@@ -8,7 +8,7 @@
 #include "nas_block.h"
 #include "flow_warp.h"
 
-extern "C" int sr_abi_version(void) { return 1; }
+extern "C" int sr_abi_version(void) { return 2; }
 
 namespace {
 
@@ -56,14 +56,15 @@ int launch_block_wgrad(const void* x, const void* dy, const void* wblob, const f
 }  // namespace
 
 extern "C" int sr_wdsr_block2_fwd(const void* x, void* ya, void* yb, const void* wa, const void* wb, const float* cia,
-                                  const float* cib, int N, int H, int W, int F, int dtype, sr_stream_t stream) {
+                                  const float* cib, void* tsa, void* tsb, int N, int H, int W, int F, int dtype,
+                                  sr_stream_t stream) {
   if (!x || !yb || !wa || !wb || !cia || !cib || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
   if (F != 24 || dtype != SR_DTYPE_BF16) return -1;
   typedef BlockCfg<24, 144, 20> C;
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
   hipLaunchKernelGGL((wdsr_block2_fwd_kernel<__bf16, 24, 144, 20>), dim3(tiles_x * tiles_y, N),
                      dim3(64 * Pair<24, 144, 20>::NWAVES), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)ya,
-                     (__bf16*)yb, (const __bf16*)wa, (const __bf16*)wb, cia, cib, H, W, tiles_x);
+                     (__bf16*)yb, (const __bf16*)wa, (const __bf16*)wb, cia, cib, (__bf16*)tsa, (__bf16*)tsb, H, W, tiles_x);
   SR_HIP_CHECK_LAUNCH();
   return 0;
 }
@@ -91,8 +92,8 @@ extern "C" int sr_wdsr_block2_fwd_repeat(void* x, void* ya, void* yb, const void
                                          const float* cib, int N, int H, int W, int F, int dtype, int reps,
                                          sr_stream_t stream) {
   for (int i = 0; i < reps; ++i) {
-    const int rc = (i & 1) ? sr_wdsr_block2_fwd(yb, ya, x, wa, wb, cia, cib, N, H, W, F, dtype, stream)
-                           : sr_wdsr_block2_fwd(x, ya, yb, wa, wb, cia, cib, N, H, W, F, dtype, stream);
+    const int rc = (i & 1) ? sr_wdsr_block2_fwd(yb, ya, x, wa, wb, cia, cib, nullptr, nullptr, N, H, W, F, dtype, stream)
+                           : sr_wdsr_block2_fwd(x, ya, yb, wa, wb, cia, cib, nullptr, nullptr, N, H, W, F, dtype, stream);
     if (rc) return rc;
   }
   return 0;
@@ -111,8 +112,8 @@ extern "C" int sr_wdsr_block_bwd_data(const void* x, const void* dy, void* dx, c
 }
 
 extern "C" int sr_wdsr_block2_bwd_data(const void* xa, const void* xb, const void* dyb, void* dxb, void* dxa,
-                                       const void* wa, const void* wb, const float* cia, const float* cib, int N,
-                                       int H, int W, int F, int dtype, sr_stream_t stream) {
+                                       const void* wa, const void* wb, const float* cia, const float* cib, void* dta,
+                                       void* dtb, int N, int H, int W, int F, int dtype, sr_stream_t stream) {
   if (!xa || !xb || !dyb || !dxb || !dxa || !wa || !wb || !cia || !cib || N <= 0 || H <= 0 || W <= 0 || N > 65535)
     return -2;
   if (F != 24 || dtype != SR_DTYPE_BF16) return -1;
@@ -120,8 +121,8 @@ extern "C" int sr_wdsr_block2_bwd_data(const void* xa, const void* xb, const voi
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
   hipLaunchKernelGGL((wdsr_block2_bwd_data_kernel<__bf16, 24, 144, 20>), dim3(tiles_x * tiles_y, N),
                      dim3(64 * C::NPT_H), 0, (hipStream_t)stream, (const __bf16*)xa, (const __bf16*)xb,
-                     (const __bf16*)dyb, (__bf16*)dxb, (__bf16*)dxa, (const __bf16*)wa, (const __bf16*)wb, cia, cib, H,
-                     W, tiles_x);
+                     (const __bf16*)dyb, (__bf16*)dxb, (__bf16*)dxa, (const __bf16*)wa, (const __bf16*)wb, cia, cib,
+                     (__bf16*)dta, (__bf16*)dtb, H, W, tiles_x);
   SR_HIP_CHECK_LAUNCH();
   return 0;
 }
@@ -140,6 +141,28 @@ extern "C" int sr_wdsr_block_wgrad(const void* x, const void* dy, const void* wb
   if (F == 32 && dtype == SR_DTYPE_F32) return SR_WG(float, 32, 192, 26);
 #undef SR_WG
   return -1;
+}
+
+extern "C" int sr_wdsr_block_wgrad_saved(const void* x, const void* dy, const void* tsave, const void* dtsave,
+                                         const void* wblob, float* pa, float* pb, int layers, int wgs, int N, int H,
+                                         int W, int F, int dtype, long x_ls, long dy_ls, long side_ls, long w_ls,
+                                         sr_stream_t stream) {
+  if (!x || !dy || !tsave || !dtsave || !wblob || !pa || !pb || layers <= 0 || wgs <= 0 || N <= 0 || H <= 0 || W <= 0 ||
+      layers > 65535)
+    return -2;
+  if (F != 24 || dtype != SR_DTYPE_BF16) return -1;
+  typedef BlockCfg<24, 144, 20> C;
+  const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
+  dim3 grid(wgs, layers);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((wdsr_block_wgrad_saved_kernel<__bf16, 24, 144, 20, 0>), grid, dim3(64 * WgradCfg<24, 144, 20, 0>::NWAVES),
+                     0, st, (const __bf16*)x, (const __bf16*)dtsave, (const __bf16*)wblob, pa, N, H, W, tiles_x,
+                     tiles_x * tiles_y, x_ls, side_ls, w_ls);
+  hipLaunchKernelGGL((wdsr_block_wgrad_saved_kernel<__bf16, 24, 144, 20, 1>), grid, dim3(64 * WgradCfg<24, 144, 20, 1>::NWAVES),
+                     0, st, (const __bf16*)dy, (const __bf16*)tsave, (const __bf16*)wblob, pb, N, H, W, tiles_x,
+                     tiles_x * tiles_y, dy_ls, side_ls, w_ls);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int sr_wdsr_block_wgrad_stamps(const void* x, const void* dy, const void* wblob, const float* cinit,
@@ -433,6 +456,17 @@ template <typename T> int net_pack(const sr_wdsr_net_t* n, hipStream_t st) {
 }
 }  // namespace
 
+// t / dt of every block are kept for the weight-gradient kernels when every block runs through the
+// two-block kernels (bf16, F = 24, even block count) and the caller provided both buffers
+static bool net_saves_side_images(const sr_wdsr_net_t* n, bool backward) {
+  return n->F == 24 && n->dtype == SR_DTYPE_BF16 && (n->NB % 2) == 0 && n->tsave && (!backward || n->dtsave);
+}
+static size_t side_image_bytes(const sr_wdsr_net_t* n) {     // one block's [N][tiles][288][LP] image
+  typedef BlockCfg<24, 144, 20> C;
+  const size_t tiles = (size_t)((n->W + C::TW - 1) / C::TW) * ((n->H + C::TH - 1) / C::TH);
+  return (size_t)n->N * tiles * C::TH * C::TW * C::LP * 2;
+}
+
 extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int save_acts, sr_stream_t stream) {
   if (!n || !n->flat || !n->src || !n->x || !n->acts || !n->out) return -2;
   hipStream_t st = (hipStream_t)stream;
@@ -445,14 +479,17 @@ extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int save_acts, sr_str
   if ((rc = sr_head_fwd(n->x, acts, n->blob_head, n->mean, n->N, n->H, n->W, n->F, n->dtype, stream))) return rc;
   char* cur = acts;
   const bool pairs = n->F == 24 && n->dtype == SR_DTYPE_BF16;   // two blocks per launch
+  const bool saved = net_saves_side_images(n, false);
+  const size_t side = side_image_bytes(n);
   for (int i = 0; i < n->NB; ++i) {
     if (pairs && i + 1 < n->NB) {
       char* mid = save_acts ? acts + (size_t)(i + 1) * act : nullptr;   // inference keeps nothing
       char* nxt = save_acts ? acts + (size_t)(i + 2) * act : (cur == acts ? acts + act : acts);
+      char* ts = (save_acts && saved) ? (char*)n->tsave : nullptr;
       if ((rc = sr_wdsr_block2_fwd(cur, mid, nxt, (char*)n->blob_body + i * blob, (char*)n->blob_body + (i + 1) * blob,
                                    n->cinit_body + (size_t)i * n->n_idx_cinit,
-                                   n->cinit_body + (size_t)(i + 1) * n->n_idx_cinit, n->N, n->H, n->W, n->F, n->dtype,
-                                   stream)))
+                                   n->cinit_body + (size_t)(i + 1) * n->n_idx_cinit, ts ? ts + (size_t)i * side : nullptr,
+                                   ts ? ts + (size_t)(i + 1) * side : nullptr, n->N, n->H, n->W, n->F, n->dtype, stream)))
         return rc;
       cur = nxt;
       ++i;
@@ -484,14 +521,18 @@ extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) 
                           n->W, n->F, n->R, n->dtype, stream)))
     return rc;
   const bool pairs = n->F == 24 && n->dtype == SR_DTYPE_BF16;   // two blocks per launch
+  const bool saved = net_saves_side_images(n, true);
+  const size_t side = side_image_bytes(n);
   for (int i = n->NB - 1; i >= 0; --i) {
     if (pairs && i >= 1) {
       if ((rc = sr_wdsr_block2_bwd_data(acts + (size_t)(i - 1) * act, acts + (size_t)i * act, grads + (size_t)(i + 1) * act,
                                         grads + (size_t)i * act, grads + (size_t)(i - 1) * act,
                                         (char*)n->blob_body + (i - 1) * blob, (char*)n->blob_body + i * blob,
                                         n->cinit_body + (size_t)(i - 1) * n->n_idx_cinit,
-                                        n->cinit_body + (size_t)i * n->n_idx_cinit, n->N, n->H, n->W, n->F, n->dtype,
-                                        stream)))
+                                        n->cinit_body + (size_t)i * n->n_idx_cinit,
+                                        saved ? (char*)n->dtsave + (size_t)(i - 1) * side : nullptr,
+                                        saved ? (char*)n->dtsave + (size_t)i * side : nullptr, n->N, n->H, n->W, n->F,
+                                        n->dtype, stream)))
         return rc;
       --i;
       continue;
@@ -501,9 +542,14 @@ extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) 
                                      n->H, n->W, n->F, n->dtype, stream)))
       return rc;
   }
-  if ((rc = sr_wdsr_block_wgrad(acts, grads + act, n->blob_body, n->cinit_body, n->part_a, n->part_b, n->NB,
-                                n->wgs_body, n->N, n->H, n->W, n->F, n->dtype, act_e, act_e, (long)n->n_idx_body,
-                                (long)n->n_idx_cinit, stream)))
+  if (saved) {
+    if ((rc = sr_wdsr_block_wgrad_saved(acts, grads + act, n->tsave, n->dtsave, n->blob_body, n->part_a, n->part_b, n->NB,
+                                        n->wgs_body, n->N, n->H, n->W, n->F, n->dtype, act_e, act_e,
+                                        (long)(side / esz), (long)n->n_idx_body, stream)))
+      return rc;
+  } else if ((rc = sr_wdsr_block_wgrad(acts, grads + act, n->blob_body, n->cinit_body, n->part_a, n->part_b, n->NB,
+                                       n->wgs_body, n->N, n->H, n->W, n->F, n->dtype, act_e, act_e, (long)n->n_idx_body,
+                                       (long)n->n_idx_cinit, stream)))
     return rc;
   if ((rc = sr_head_wgrad(grads, n->x, n->mean, n->part_head, n->wgs_head, n->N, n->H, n->W, n->F, n->dtype, stream)))
     return rc;
@@ -584,4 +630,67 @@ extern "C" int sr_probe_copy(const void* src, void* dst, size_t n_bytes, sr_stre
                      (u32x4*)dst, n_bytes / 16);
   SR_HIP_CHECK_LAUNCH();
   return 0;
+}
+
+// launch-floor probe: `reps` dependent launches of a kernel that does nothing but occupy `threads` threads and
+// `lds_bytes` of LDS per workgroup (so one workgroup per CU when large) and write one word per workgroup
+__global__ void probe_floor_kernel(unsigned* out) {
+  extern __shared__ unsigned dyn_lds[];
+  if (threadIdx.x == 0) {
+    dyn_lds[0] = blockIdx.x;
+    out[blockIdx.x + gridDim.x * blockIdx.y] = dyn_lds[0];
+  }
+}
+extern "C" int sr_probe_launch_floor(void* out, int gx, int gy, int threads, int lds_bytes, int reps,
+                                     sr_stream_t stream) {
+  if (!out || gx <= 0 || gy <= 0 || threads <= 0 || threads > 1024 || lds_bytes < 4 || lds_bytes > 160 * 1024) return -2;
+  if (hipFuncSetAttribute((const void*)probe_floor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    return -3;
+  for (int i = 0; i < reps; ++i)
+    hipLaunchKernelGGL(probe_floor_kernel, dim3(gx, gy), dim3(threads), lds_bytes, (hipStream_t)stream, (unsigned*)out);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+
+// same chain captured once in a hipGraph and replayed: separates the host's launch rate from the GPU's
+// dependent-dispatch cost.  Synchronises; returns microseconds per kernel in *us_per_launch.
+extern "C" int sr_probe_launch_floor_graph(void* out, int gx, int gy, int threads, int lds_bytes, int reps, int iters,
+                                           float* us_per_launch) {
+  if (!out || !us_per_launch || gx <= 0 || gy <= 0 || threads <= 0 || threads > 1024 || lds_bytes < 4 ||
+      lds_bytes > 160 * 1024 || reps <= 0 || iters <= 0)
+    return -2;
+  if (hipFuncSetAttribute((const void*)probe_floor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    return -3;
+  hipStream_t s;
+  hipGraph_t g;
+  hipGraphExec_t ge;
+  hipEvent_t e0, e1;
+  int rc = -3;
+  if (hipStreamCreate(&s) != hipSuccess) return -3;
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+    for (int i = 0; i < reps; ++i)
+      hipLaunchKernelGGL(probe_floor_kernel, dim3(gx, gy), dim3(threads), lds_bytes, s, (unsigned*)out);
+    if (hipStreamEndCapture(s, &g) == hipSuccess) {
+      if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess) {
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        hipGraphLaunch(ge, s);
+        hipStreamSynchronize(s);
+        hipEventRecord(e0, s);
+        for (int i = 0; i < iters; ++i) hipGraphLaunch(ge, s);
+        hipEventRecord(e1, s);
+        hipStreamSynchronize(s);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        *us_per_launch = ms * 1e3f / ((float)reps * iters);
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        hipGraphExecDestroy(ge);
+        rc = 0;
+      }
+      hipGraphDestroy(g);
+    }
+  }
+  hipStreamDestroy(s);
+  return rc;
 }

@@ -76,6 +76,10 @@ template <typename T> SR_DEV typename FragOf<T>::half_type acc_group(const f32x1
   return v;
 }
 
+// activation stores bypass the per-XCD L2 write-back path: nothing of ours re-reads them before the kernel
+// ends, and the end-of-kernel release then has no dirty lines left to flush
+template <typename V> SR_DEV void stream_store(V* p, const V& v) { __builtin_nontemporal_store(v, p); }
+
 SR_DEV f32x16 zero16() {
   f32x16 z;
 #pragma unroll

@@ -162,7 +162,7 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block_fw
     if (Y < H && X < W) {
       T* yo = y + (((size_t)n * H + Y) * W + X) * F;
 #pragma unroll
-      for (int g = 0; g < C::FC; ++g) *reinterpret_cast<HalfT*>(yo + g * 8 + hh * 4) = acc_group<T>(oacc, g);
+      for (int g = 0; g < C::FC; ++g) stream_store(reinterpret_cast<HalfT*>(yo + g * 8 + hh * 4), acc_group<T>(oacc, g));
     }
   }
   SR_STAMP(5);
@@ -392,7 +392,7 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_O)) void wdsr_block_bw
     if (Y < H && X < W) {
       T* o = dx + img + ((size_t)Y * W + X) * F;
 #pragma unroll
-      for (int g = 0; g < C::FC; ++g) *reinterpret_cast<HalfT*>(o + g * 8 + hh * 4) = acc_group<T>(dxacc, g);
+      for (int g = 0; g < C::FC; ++g) stream_store(reinterpret_cast<HalfT*>(o + g * 8 + hh * 4), acc_group<T>(dxacc, g));
     }
   }
 }
@@ -740,8 +740,8 @@ SR_DEV f32x16 y_from_t(const T* Timg, int trow, int tstride, const T* Ximg, int 
 template <typename T, int F, int E, int L>
 __global__ __launch_bounds__((64 * Pair<F, E, L>::NWAVES)) void wdsr_block2_fwd_kernel(
     const T* __restrict__ x, T* __restrict__ ya, T* __restrict__ yb, const T* __restrict__ wa,
-    const T* __restrict__ wb, const float* __restrict__ cia, const float* __restrict__ cib, int H, int W,
-    int tiles_x) {
+    const T* __restrict__ wb, const float* __restrict__ cia, const float* __restrict__ cib, T* __restrict__ tsa,
+    T* __restrict__ tsb, int H, int W, int tiles_x) {
   typedef BlockCfg<F, E, L> C;
   typedef Pair<F, E, L> P;
   typedef typename FragOf<T>::type FragT;
@@ -756,6 +756,7 @@ __global__ __launch_bounds__((64 * Pair<F, E, L>::NWAVES)) void wdsr_block2_fwd_
   const int n = blockIdx.y, tile = blockIdx.x;
   const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
   const size_t img = (size_t)n * H * W * F;
+  const size_t tile_g = (size_t)n * gridDim.x + tile;            // tile index of the saved t images
 
   // ---- stage: both weight sets, x on the 2-pixel-halo region (zero outside the image, ones channel) ----
   stage_weights<T, NTHREADS>(WL, wa, C::NFRAG_FWD, tid);
@@ -813,6 +814,8 @@ __global__ __launch_bounds__((64 * Pair<F, E, L>::NWAVES)) void wdsr_block2_fwd_
         for (int j = 0; j < 4; ++j) v[j] = (T)0.f;
       }
       *reinterpret_cast<HalfT*>(TT + hp2 * C::LP + g * 8 + hh * 4) = v;
+      if (tsa && hy >= 2 && hy < 2 + C::TH && hx >= 2 && hx < 2 + C::TW)
+        stream_store(reinterpret_cast<HalfT*>(tsa + (tile_g * (C::TH * C::TW) + (hy - 2) * C::TW + hx - 2) * C::LP + g * 8 + hh * 4), v);
     }
   }
   __syncthreads();
@@ -831,7 +834,7 @@ __global__ __launch_bounds__((64 * Pair<F, E, L>::NWAVES)) void wdsr_block2_fwd_
       if (ya && hy >= 1 && hy <= C::TH && hx >= 1 && hx <= C::TW && Y < H && X < W) {
         T* o = ya + img + ((size_t)Y * W + X) * F;
 #pragma unroll
-        for (int g = 0; g < C::FC; ++g) *reinterpret_cast<HalfT*>(o + g * 8 + hh * 4) = acc_group<T>(oacc, g);
+        for (int g = 0; g < C::FC; ++g) stream_store(reinterpret_cast<HalfT*>(o + g * 8 + hh * 4), acc_group<T>(oacc, g));
       }
     }
   }
@@ -847,6 +850,8 @@ __global__ __launch_bounds__((64 * Pair<F, E, L>::NWAVES)) void wdsr_block2_fwd_
       valid = (Y >= 0 && Y < H && X >= 0 && X < W);
     }
     const f32x16 tacc = t_from_x<T, C>(XB, hp1, wsb, cib, lane);
+    const int hy1 = hp1 / C::HW, hx1 = hp1 - hy1 * C::HW;
+    const bool core = tsb && hp1 < C::NPXH && hy1 >= 1 && hy1 <= C::TH && hx1 >= 1 && hx1 <= C::TW;
 #pragma unroll
     for (int g = 0; g < C::CPT; ++g) {
       HalfT v = acc_group<T>(tacc, g);
@@ -855,6 +860,8 @@ __global__ __launch_bounds__((64 * Pair<F, E, L>::NWAVES)) void wdsr_block2_fwd_
         for (int j = 0; j < 4; ++j) v[j] = (T)0.f;
       }
       *reinterpret_cast<HalfT*>(TT + hp1 * C::LP + g * 8 + hh * 4) = v;
+      if (core)
+        stream_store(reinterpret_cast<HalfT*>(tsb + (tile_g * (C::TH * C::TW) + (hy1 - 1) * C::TW + hx1 - 1) * C::LP + g * 8 + hh * 4), v);
     }
   }
   __syncthreads();
@@ -868,7 +875,7 @@ __global__ __launch_bounds__((64 * Pair<F, E, L>::NWAVES)) void wdsr_block2_fwd_
     if (Y < H && X < W) {
       T* o = yb + img + ((size_t)Y * W + X) * F;
 #pragma unroll
-      for (int g = 0; g < C::FC; ++g) *reinterpret_cast<HalfT*>(o + g * 8 + hh * 4) = acc_group<T>(oacc, g);
+      for (int g = 0; g < C::FC; ++g) stream_store(reinterpret_cast<HalfT*>(o + g * 8 + hh * 4), acc_group<T>(oacc, g));
     }
   }
 }
@@ -973,7 +980,7 @@ template <typename T, int F, int E, int L>
 __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block2_bwd_data_kernel(
     const T* __restrict__ xa, const T* __restrict__ xb, const T* __restrict__ dyb, T* __restrict__ dxb,
     T* __restrict__ dxa, const T* __restrict__ wa, const T* __restrict__ wb, const float* __restrict__ cia,
-    const float* __restrict__ cib, int H, int W, int tiles_x) {
+    const float* __restrict__ cib, T* __restrict__ dta, T* __restrict__ dtb, int H, int W, int tiles_x) {
   typedef BlockCfg<F, E, L> C;
   typedef BwdCfg<C> B;
   typedef Pair<F, E, L> P;
@@ -993,6 +1000,7 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block2_b
   const int n = blockIdx.y, tile = blockIdx.x;
   const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
   const size_t img = (size_t)n * H * W * F;
+  const size_t tile_g = (size_t)n * gridDim.x + tile;            // tile index of the saved dt images
 
   WSrc<T, true> wsa, wsb;
   wsa.p = WL;
@@ -1027,6 +1035,18 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block2_b
     if (live) {
       const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
       const bool inimg = (Y >= 0 && Y < H && X >= 0 && X < W);
+      if (dtb && hy >= 1 && hy <= C::TH && hx >= 1 && hx <= C::TW) {
+        T* o = dtb + (tile_g * B::NPXC + (hy - 1) * C::TW + hx - 1) * C::LP;
+#pragma unroll
+        for (int g = 0; g < C::CPT; ++g) {
+          HalfT v = acc_group<T>(dtacc, g);
+          if (!inimg) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (T)0.f;
+          }
+          stream_store(reinterpret_cast<HalfT*>(o + g * 8 + hh * 4), v);
+        }
+      }
 #pragma unroll
       for (int g = 0; g < C::FC; ++g) {
         HalfT v = acc_group<T>(dxacc, g);
@@ -1039,7 +1059,7 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block2_b
       if (inimg && hy >= 1 && hy <= C::TH && hx >= 1 && hx <= C::TW) {
         T* o = dxb + img + ((size_t)Y * W + X) * F;
 #pragma unroll
-        for (int g = 0; g < C::FC; ++g) *reinterpret_cast<HalfT*>(o + g * 8 + hh * 4) = acc_group<T>(dxacc, g);
+        for (int g = 0; g < C::FC; ++g) stream_store(reinterpret_cast<HalfT*>(o + g * 8 + hh * 4), acc_group<T>(dxacc, g));
       }
     }
   }
@@ -1055,10 +1075,212 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block2_b
     const f32x16 dtacc = dt_from_dy<T, C>(DY1, hbase, C::HW, wsa, LW3T, lane);
     const f32x16 dxacc = dx_from_dt<T, C>(dtacc, XA, pc, DY1, (hbase + C::HW + 1) * C::F, wsa, LW2T, LW1T, LID, cia, lane);
     const int Y = ty0 + oy, X = tx0 + ox;
+    if (dta) {
+      T* o = dta + (tile_g * B::NPXC + pc) * C::LP;
+#pragma unroll
+      for (int g = 0; g < C::CPT; ++g) {
+        HalfT v = acc_group<T>(dtacc, g);
+        if (!(Y < H && X < W)) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (T)0.f;
+        }
+        stream_store(reinterpret_cast<HalfT*>(o + g * 8 + hh * 4), v);
+      }
+    }
     if (Y < H && X < W) {
       T* o = dxa + img + ((size_t)Y * W + X) * F;
 #pragma unroll
-      for (int g = 0; g < C::FC; ++g) *reinterpret_cast<HalfT*>(o + g * 8 + hh * 4) = acc_group<T>(dxacc, g);
+      for (int g = 0; g < C::FC; ++g) stream_store(reinterpret_cast<HalfT*>(o + g * 8 + hh * 4), acc_group<T>(dxacc, g));
     }
+  }
+}
+
+// =============================================================================================
+// weight gradients from SAVED intermediates (bf16, F = 24, networks run through the two-block kernels):
+// the forward pair kernel keeps t (the 3x3 conv's input) and the backward pair kernel keeps dt (the gradient
+// at the 3x3 conv's input) of every core pixel, tile-local [tile][288][LP].  HBM has ~85 % headroom in this
+// path while the recompute phases and their barriers were half of the weight-gradient time, so
+//   ROLE 0: x core tile + dt image -> dW1, dW2, db1, db2     (no dy halo, no transposed 3x3, one barrier/tile)
+//   ROLE 1: t image + dy halo tile -> dW3 (+ b3 via t's ones channel)   (no weights at all)
+// Slab layouts are those of wdsr_block_wgrad_kernel.
+// =============================================================================================
+template <typename T, int F, int E, int L, int ROLE>
+__global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_block_wgrad_saved_kernel(
+    const T* __restrict__ act, const T* __restrict__ side, const T* __restrict__ wblob, float* __restrict__ partial,
+    int N, int H, int W, int tiles_x, int tiles_per_img, long act_ls, long side_ls, long w_ls) {
+  typedef BlockCfg<F, E, L> C;
+  typedef BwdCfg<C> B;
+  typedef WgradCfg<F, E, L, ROLE> G;
+  typedef typename FragOf<T>::type FragT;
+  static_assert(sizeof(T) == 2 && C::FOLD_B1, "saved-image weight gradients: bf16, bias folded through the ones channel");
+  constexpr int NTHREADS = 64 * G::NWAVES;
+  constexpr int IMG_ELEMS = (B::NPXC + 1) * 32;                       // dt or t image: [core px][32 ch]
+  constexpr int ACT_ELEMS = ROLE == 0 ? B::XC_ELEMS : B::DY_ELEMS;     // x core tile / dy halo tile
+  constexpr int TILE_ELEMS = IMG_ELEMS + ACT_ELEMS;
+  constexpr int NW1 = C::NET * C::KS1, LW2N = NW1;
+  constexpr int NWL = ROLE == 0 ? NW1 + 2 * C::NET : 0;
+  constexpr int SLAB = ROLE == 0 ? B::SLAB_A : B::SLAB_B;
+  constexpr int NSIDE = B::NPXC * C::CPT, IS = (NSIDE + NTHREADS - 1) / NTHREADS;     // 16-byte chunks of a saved image
+  constexpr int STAGE_BYTES = (2 * TILE_ELEMS + NWL * 512) * (int)sizeof(T);
+  constexpr int RED_BYTES = ROLE == 0 ? (2 * SLAB + IS * NTHREADS * 8 + 8 * 32) * 4 : 0;
+  constexpr int LDS_BYTES = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES];
+  T* const BUF = reinterpret_cast<T*>(smem_raw);                       // [2][IMG | ACT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+
+  const int layer = blockIdx.y;
+  act += (size_t)layer * act_ls;
+  side += (size_t)layer * side_ls;
+  WSrc<T, true> wsrc;
+  if constexpr (ROLE == 0) {
+    wblob += (size_t)layer * w_ls;
+    T* wl = BUF + 2 * TILE_ELEMS;
+    stage_weights<T, NTHREADS>(wl, wblob, NW1, tid);
+    stage_weights<T, NTHREADS>(wl + NW1 * 512, wblob + (size_t)B::W2N_OFF * 512, 2 * C::NET, tid);
+    wsrc.p = wl;
+  }
+  // channels LP..31 and the slack row of both images are never written by the staging: zero them once
+  for (int i = tid; i < 2 * (B::NPXC + 1); i += NTHREADS) {
+    T* row = BUF + (i / (B::NPXC + 1)) * TILE_ELEMS + (i % (B::NPXC + 1)) * 32;
+    const int c0 = (i % (B::NPXC + 1)) == B::NPXC ? 0 : C::LP;
+    for (int c = c0; c < 32; ++c) row[c] = (T)0.f;
+  }
+
+  f32x16 accA = zero16(), accB = zero16();          // ROLE 0: dW1^T[et], dW2[et].  ROLE 1: accA = dW3^T[tap = wave]
+  float s2[IS][8];                                  // ROLE 0: per-thread sums of the dt chunks it stages (-> db2)
+#pragma unroll
+  for (int it = 0; it < IS; ++it)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s2[it][j] = 0.f;
+  float db1 = 0.f;
+  const int et = wave >> 1, half = wave & 1;
+
+  const int total = N * tiles_per_img;
+  FragT vs[IS];
+  RegionRegs<T, NTHREADS, (ROLE == 0 ? C::TW : C::HW), (ROLE == 0 ? B::NPXC + 1 : C::NPXH_PAD + 2),
+             (ROLE == 0 ? B::NPXC : C::NPXH), (ROLE == 0 ? C::KX / 8 : C::FC), C::FC, ROLE == 0> ra;
+  auto fetch = [&](int t) {
+    const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
+    int tid2 = tid;
+    asm volatile("" : "+v"(tid2));                     // keep the per-thread indices out of long-lived registers
+    const T* sp = side + (size_t)t * (B::NPXC * C::LP);
+#pragma unroll
+    for (int it = 0; it < IS; ++it) {
+      const int idx = tid2 + it * NTHREADS;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vs[it][j] = (T)0.f;
+      if (idx < NSIDE) vs[it] = *reinterpret_cast<const FragT*>(sp + (size_t)idx * 8);
+    }
+    const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+    ra.load(act + (size_t)n * H * W * F, H, W, ROLE == 0 ? ty0 : ty0 - 1, ROLE == 0 ? tx0 : tx0 - 1, tid2);
+  };
+  auto store = [&](int buf) {
+    T* IMGb = BUF + buf * TILE_ELEMS;
+#pragma unroll
+    for (int it = 0; it < IS; ++it) {
+      const int idx = tid + it * NTHREADS;
+      if (idx < NSIDE) {
+        *reinterpret_cast<FragT*>(IMGb + (idx / C::CPT) * 32 + (idx % C::CPT) * 8) = vs[it];
+        if constexpr (ROLE == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s2[it][j] += (float)vs[it][j];
+        }
+      }
+    }
+    ra.store(IMGb + IMG_ELEMS, tid);
+  };
+  int cur = 0;
+  if ((int)blockIdx.x < total) {
+    fetch(blockIdx.x);
+    store(0);
+  }
+  for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    const bool has_next = t + (int)gridDim.x < total;
+    const T* IMG = BUF + cur * TILE_ELEMS;
+    const T* ACT = IMG + IMG_ELEMS;
+    __syncthreads();                                   // tile t staged; the other buffer is free
+    if (has_next) fetch(t + gridDim.x);
+    if constexpr (ROLE == 0) {
+      const T* XC = ACT;
+#pragma unroll 1
+      for (int ot = half; ot < C::NPT_O; ot += 2) {
+        const int toy = (ot / (C::TW / 8)) * 4, tox = (ot % (C::TW / 8)) * 8;
+        const int pc = (toy + (r >> 3)) * C::TW + tox + (r & 7);
+        auto rowx = [=](int p) { return ((toy + (p >> 3)) * C::TW + tox + (p & 7)) * C::KX; };
+        auto rowi = [=](int p) { return ((toy + (p >> 3)) * C::TW + tox + (p & 7)) * 32; };
+        f32x16 h2 = zero16();
+#pragma unroll
+        for (int s = 0; s < C::KS1; ++s)
+          h2 = mma16<T>(lds_chunk<T>(XC, pc * C::KX + (2 * s + hh) * 8), wsrc.get(C::W1_OFF + et * C::KS1 + s, lane), h2);
+        f32x16 dh2 = zero16();
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          dh2 = mma16<T>(lds_chunk<T>(IMG, pc * 32 + (2 * s + hh) * 8), wsrc.get(LW2N + 2 * et + s, lane), dh2);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          dh2[i] = h2[i] > 0.f ? dh2[i] : 0.f;
+          sum += dh2[i];
+        }
+        db1 += sum;
+        accA = mma16<T>(tr_frag<T>(XC, 0, lane, rowx), acc_to_frag<T, 0>(dh2), accA);
+        accA = mma16<T>(tr_frag<T>(XC, 1, lane, rowx), acc_to_frag<T, 1>(dh2), accA);
+        accB = mma16<T>(tr_frag<T>(IMG, 0, lane, rowi), acc_to_frag_relu<T, 0>(h2), accB);
+        accB = mma16<T>(tr_frag<T>(IMG, 1, lane, rowi), acc_to_frag_relu<T, 1>(h2), accB);
+      }
+    } else {
+      const T* DYs = ACT;
+      const int uy = wave / 3, ux = wave - uy * 3;    // tap u = wave
+#pragma unroll 3
+      for (int ot = 0; ot < C::NPT_O; ++ot) {
+        const int toy = (ot / (C::TW / 8)) * 4, tox = (ot % (C::TW / 8)) * 8;
+        auto rowi = [=](int p) { return ((toy + (p >> 3)) * C::TW + tox + (p & 7)) * 32; };
+        auto rowd = [=](int p) { return ((toy + (p >> 3) + uy) * C::HW + tox + (p & 7) + ux) * C::F; };
+        accA = mma16<T>(tr_frag<T>(IMG, 0, lane, rowi), tr_frag<T>(DYs, 0, lane, rowd), accA);
+        accA = mma16<T>(tr_frag<T>(IMG, 1, lane, rowi), tr_frag<T>(DYs, 1, lane, rowd), accA);
+      }
+    }
+    if (has_next) {
+      cur ^= 1;
+      store(cur);
+    }
+  }
+
+  float* out = partial + ((size_t)layer * gridDim.x + blockIdx.x) * SLAB;
+  if constexpr (ROLE == 0) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem_raw);
+    float* mine = red + half * SLAB;
+    float* P = red + 2 * SLAB;                        // [IS * NTHREADS][8] per-chunk dt sums
+    float* Q = P + IS * NTHREADS * 8;                 // [8 parts][32]
+    slab_store_tile(mine, et, accA, lane);
+    slab_store_tile(mine, C::NET + et, accB, lane);
+    const float d1 = db1 + __shfl_xor(db1, 32);
+    if (hh == 0) mine[2 * C::NET * 1024 + et * 32 + r] = d1;
+#pragma unroll
+    for (int it = 0; it < IS; ++it)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) P[(size_t)(tid + it * NTHREADS) * 8 + j] = s2[it][j];
+    __syncthreads();
+    constexpr int NSUM = 2 * C::NET * 1024 + C::NET * 32;
+    for (int i = tid; i < NSUM; i += NTHREADS) out[i] = red[i] + red[SLAB + i];
+    if (tid < 8 * C::LP) {                            // db2[ch] = sum over pixels of chunk (px * CPT + ch / 8), element ch % 8
+      const int part = tid / C::LP, ch = tid - part * C::LP;
+      constexpr int PER = (B::NPXC + 7) / 8;
+      float v = 0.f;
+      for (int px = part * PER; px < (part + 1) * PER && px < B::NPXC; ++px) v += P[(size_t)(px * C::CPT + (ch >> 3)) * 8 + (ch & 7)];
+      Q[part * 32 + ch] = v;
+    }
+    __syncthreads();
+    if (tid < 32) {
+      float v = 0.f;
+      if (tid < C::LP) {
+#pragma unroll
+        for (int part = 0; part < 8; ++part) v += Q[part * 32 + tid];
+      }
+      out[NSUM + tid] = v;
+    }
+  } else {
+    slab_store_tile(out, wave, accA, lane);
   }
 }

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void sr_head_fwd_kernel(const float* __restric
     if (Y < H && X < W) {
       T* yo = y + (((size_t)n * H + Y) * W + X) * F;
 #pragma unroll
-      for (int g = 0; g < E::FC; ++g) *reinterpret_cast<HalfT*>(yo + g * 8 + hh * 4) = acc_group<T>(acc, g);
+      for (int g = 0; g < E::FC; ++g) stream_store(reinterpret_cast<HalfT*>(yo + g * 8 + hh * 4), acc_group<T>(acc, g));
     }
   }
 }
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void sr_tail_bwd_data_kernel(const float* __re
     if (Y < H && X < W) {
       T* o = dfeat + (((size_t)n * H + Y) * W + X) * F;
 #pragma unroll
-      for (int g = 0; g < E::FC; ++g) *reinterpret_cast<HalfT*>(o + g * 8 + hh * 4) = acc_group<T>(acc, g);
+      for (int g = 0; g < E::FC; ++g) stream_store(reinterpret_cast<HalfT*>(o + g * 8 + hh * 4), acc_group<T>(acc, g));
     }
   }
 }

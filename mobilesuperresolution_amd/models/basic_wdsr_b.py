@@ -184,8 +184,24 @@ class BASIC_MODEL(nn.Module):
         net = st.net
         net.N, net.H, net.W = n, h, w
         net.flat, net.x, net.acts, net.out = flat.data_ptr(), x.data_ptr(), acts.data_ptr(), out.data_ptr()
+        side = None
+        if save_acts and self._saves_side_images():
+            side = torch.empty(self._side_shape(n, h, w), dtype=self.hot_dtype, device=x.device)
+        net.tsave = side.data_ptr() if side is not None else None
+        net.dtsave = None
         L.launch("sr_wdsr_net_forward", L.lib().sr_wdsr_net_forward, ctypes.byref(net), int(save_acts), L.stream_ptr())
-        return out, acts
+        return out, acts, side
+
+    def _saves_side_images(self) -> bool:
+        """bf16 / 24 units / even block count: the two-block kernels keep t (forward) and dt (backward) of every
+        block so the weight-gradient kernels need not recompute them (csrc/wdsr_block.h)."""
+        lay = self.layout
+        return (self.hot_dtype == torch.bfloat16 and lay.F == 24 and lay.NB % 2 == 0 and lay.NB > 0
+                and os.environ.get("SR_RECOMPUTE_WGRAD", "0") != "1")
+
+    def _side_shape(self, n, h, w):
+        tiles = ((h + 11) // 12) * ((w + 23) // 24)
+        return (self.layout.NB, n, tiles, 288, 24)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._check_input(x)
@@ -201,8 +217,8 @@ class _NetFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, flat, model):
-        out, acts = model._forward_impl(x, flat, True)
-        ctx.model, ctx.x, ctx.acts, ctx.flat = model, x, acts, flat
+        out, acts, tsave = model._forward_impl(x, flat, True)
+        ctx.model, ctx.x, ctx.acts, ctx.flat, ctx.tsave = model, x, acts, flat, tsave
         return out
 
     @staticmethod
@@ -216,5 +232,8 @@ class _NetFunction(torch.autograd.Function):
         net.N, net.H, net.W = x.shape[0], x.shape[2], x.shape[3]
         net.flat, net.gflat, net.x = flat.data_ptr(), gflat.data_ptr(), x.data_ptr()
         net.acts, net.grads, net.dout = acts.data_ptr(), grads.data_ptr(), dout.data_ptr()
+        dtsave = torch.empty_like(ctx.tsave) if ctx.tsave is not None else None
+        net.tsave = ctx.tsave.data_ptr() if ctx.tsave is not None else None
+        net.dtsave = dtsave.data_ptr() if dtsave is not None else None
         L.launch("sr_wdsr_net_backward", L.lib().sr_wdsr_net_backward, ctypes.byref(net), L.stream_ptr())
         return None, gflat, None

@@ -185,7 +185,7 @@ def test_block_pair_kernel_bit_identical_to_two_launches(shape):
     HP.block_fwd(y1, y2, blob[1], cinit[1])
     p1, p2 = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
     L.check(L.lib().sr_wdsr_block2_fwd(x.data_ptr(), p1.data_ptr(), p2.data_ptr(), blob[0].data_ptr(), blob[1].data_ptr(),
-                                       cinit[0].data_ptr(), cinit[1].data_ptr(), n, h, w, f, 1, L.stream_ptr()), "pair")
+                                       cinit[0].data_ptr(), cinit[1].data_ptr(), None, None, n, h, w, f, 1, L.stream_ptr()), "pair")
     torch.cuda.synchronize()
     assert torch.equal(p1, y1) and torch.equal(p2, y2)
 
@@ -209,6 +209,6 @@ def test_block_pair_bwd_data_bit_identical_to_two_launches(shape):
     p1, p0 = torch.full_like(xa, float("nan")), torch.full_like(xa, float("nan"))
     L.check(L.lib().sr_wdsr_block2_bwd_data(xa.data_ptr(), xb.data_ptr(), dyb.data_ptr(), p1.data_ptr(), p0.data_ptr(),
                                             blob[0].data_ptr(), blob[1].data_ptr(), cinit[0].data_ptr(), cinit[1].data_ptr(),
-                                            n, h, w, f, 1, L.stream_ptr()), "pair bwd")
+                                            None, None, n, h, w, f, 1, L.stream_ptr()), "pair bwd")
     torch.cuda.synchronize()
     assert torch.equal(p1, d1) and torch.equal(p0, d0)
