@@ -155,10 +155,10 @@ extern "C" int sr_wdsr_block_wgrad_saved(const void* x, const void* dy, const vo
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
   dim3 grid(wgs, layers);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL((wdsr_block_wgrad_saved_kernel<__bf16, 24, 144, 20, 0>), grid, dim3(64 * WgradCfg<24, 144, 20, 0>::NWAVES),
+  hipLaunchKernelGGL((wdsr_block_wgrad_saved_kernel<__bf16, 24, 144, 20, 0>), grid, dim3(64 * WgradSavedCfg<24, 144, 20, 0>::NWAVES),
                      0, st, (const __bf16*)x, (const __bf16*)dtsave, (const __bf16*)wblob, pa, N, H, W, tiles_x,
                      tiles_x * tiles_y, x_ls, side_ls, w_ls);
-  hipLaunchKernelGGL((wdsr_block_wgrad_saved_kernel<__bf16, 24, 144, 20, 1>), grid, dim3(64 * WgradCfg<24, 144, 20, 1>::NWAVES),
+  hipLaunchKernelGGL((wdsr_block_wgrad_saved_kernel<__bf16, 24, 144, 20, 1>), grid, dim3(64 * WgradSavedCfg<24, 144, 20, 1>::NWAVES),
                      0, st, (const __bf16*)dy, (const __bf16*)tsave, (const __bf16*)wblob, pb, N, H, W, tiles_x,
                      tiles_x * tiles_y, dy_ls, side_ls, w_ls);
   SR_HIP_CHECK_LAUNCH();

@@ -1104,13 +1104,18 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block2_b
 //   ROLE 1: t image + dy halo tile -> dW3 (+ b3 via t's ones channel)   (no weights at all)
 // Slab layouts are those of wdsr_block_wgrad_kernel.
 // =============================================================================================
+template <int F, int E, int L, int ROLE> struct WgradSavedCfg {
+  static constexpr int NSPLIT = 3;                  // ROLE 0: waves per e-tile (each takes every NSPLIT-th pixel tile)
+  static constexpr int NWAVES = ROLE == 0 ? NSPLIT * BlockCfg<F, E, L>::NET : 9;
+};
+
 template <typename T, int F, int E, int L, int ROLE>
-__global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_block_wgrad_saved_kernel(
+__global__ __launch_bounds__((64 * WgradSavedCfg<F, E, L, ROLE>::NWAVES)) void wdsr_block_wgrad_saved_kernel(
     const T* __restrict__ act, const T* __restrict__ side, const T* __restrict__ wblob, float* __restrict__ partial,
     int N, int H, int W, int tiles_x, int tiles_per_img, long act_ls, long side_ls, long w_ls) {
   typedef BlockCfg<F, E, L> C;
   typedef BwdCfg<C> B;
-  typedef WgradCfg<F, E, L, ROLE> G;
+  typedef WgradSavedCfg<F, E, L, ROLE> G;
   typedef typename FragOf<T>::type FragT;
   static_assert(sizeof(T) == 2 && C::FOLD_B1, "saved-image weight gradients: bf16, bias folded through the ones channel");
   constexpr int NTHREADS = 64 * G::NWAVES;
@@ -1122,8 +1127,10 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
   constexpr int SLAB = ROLE == 0 ? B::SLAB_A : B::SLAB_B;
   constexpr int NSIDE = B::NPXC * C::CPT, IS = (NSIDE + NTHREADS - 1) / NTHREADS;     // 16-byte chunks of a saved image
   constexpr int STAGE_BYTES = (2 * TILE_ELEMS + NWL * 512) * (int)sizeof(T);
-  constexpr int RED_BYTES = ROLE == 0 ? (2 * SLAB + IS * NTHREADS * 8 + 8 * 32) * 4 : 0;
-  constexpr int LDS_BYTES = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
+  // ROLE 0: per-thread running sums of the staged dt chunks (-> db2) live in LDS behind both the staging
+  // buffers and the epilogue's partial slabs (8 VGPRs the 128-register budget does not have)
+  constexpr int P_OFF = STAGE_BYTES > G::NSPLIT * SLAB * 4 ? STAGE_BYTES : G::NSPLIT * SLAB * 4;
+  constexpr int LDS_BYTES = ROLE == 0 ? P_OFF + (IS * NTHREADS * 8 + 8 * 32) * 4 : STAGE_BYTES;
   __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES];
   T* const BUF = reinterpret_cast<T*>(smem_raw);                       // [2][IMG | ACT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
@@ -1147,13 +1154,15 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
   }
 
   f32x16 accA = zero16(), accB = zero16();          // ROLE 0: dW1^T[et], dW2[et].  ROLE 1: accA = dW3^T[tap = wave]
-  float s2[IS][8];                                  // ROLE 0: per-thread sums of the dt chunks it stages (-> db2)
+  float* const P = reinterpret_cast<float*>(smem_raw + (ROLE == 0 ? P_OFF : 0));   // [IS * NTHREADS][8]
+  if constexpr (ROLE == 0) {
 #pragma unroll
-  for (int it = 0; it < IS; ++it)
+    for (int it = 0; it < IS; ++it)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s2[it][j] = 0.f;
+      for (int j = 0; j < 8; ++j) P[(size_t)(tid + it * NTHREADS) * 8 + j] = 0.f;
+  }
   float db1 = 0.f;
-  const int et = wave >> 1, half = wave & 1;
+  const int et = wave / G::NSPLIT, half = wave % G::NSPLIT;
 
   const int total = N * tiles_per_img;
   FragT vs[IS];
@@ -1182,8 +1191,15 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
       if (idx < NSIDE) {
         *reinterpret_cast<FragT*>(IMGb + (idx / C::CPT) * 32 + (idx % C::CPT) * 8) = vs[it];
         if constexpr (ROLE == 0) {
+          f32x4* pp = reinterpret_cast<f32x4*>(P + (size_t)idx * 8);
+          f32x4 a = pp[0], b = pp[1];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) s2[it][j] += (float)vs[it][j];
+          for (int j = 0; j < 4; ++j) {
+            a[j] += (float)vs[it][j];
+            b[j] += (float)vs[it][4 + j];
+          }
+          pp[0] = a;
+          pp[1] = b;
         }
       }
     }
@@ -1203,7 +1219,7 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
     if constexpr (ROLE == 0) {
       const T* XC = ACT;
 #pragma unroll 1
-      for (int ot = half; ot < C::NPT_O; ot += 2) {
+      for (int ot = half; ot < C::NPT_O; ot += G::NSPLIT) {
         const int toy = (ot / (C::TW / 8)) * 4, tox = (ot % (C::TW / 8)) * 8;
         const int pc = (toy + (r >> 3)) * C::TW + tox + (r & 7);
         auto rowx = [=](int p) { return ((toy + (p >> 3)) * C::TW + tox + (p & 7)) * C::KX; };
@@ -1251,19 +1267,19 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem_raw);
     float* mine = red + half * SLAB;
-    float* P = red + 2 * SLAB;                        // [IS * NTHREADS][8] per-chunk dt sums
     float* Q = P + IS * NTHREADS * 8;                 // [8 parts][32]
     slab_store_tile(mine, et, accA, lane);
     slab_store_tile(mine, C::NET + et, accB, lane);
     const float d1 = db1 + __shfl_xor(db1, 32);
     if (hh == 0) mine[2 * C::NET * 1024 + et * 32 + r] = d1;
-#pragma unroll
-    for (int it = 0; it < IS; ++it)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) P[(size_t)(tid + it * NTHREADS) * 8 + j] = s2[it][j];
     __syncthreads();
     constexpr int NSUM = 2 * C::NET * 1024 + C::NET * 32;
-    for (int i = tid; i < NSUM; i += NTHREADS) out[i] = red[i] + red[SLAB + i];
+    for (int i = tid; i < NSUM; i += NTHREADS) {
+      float v = red[i];
+#pragma unroll
+      for (int q = 1; q < G::NSPLIT; ++q) v += red[q * SLAB + i];
+      out[i] = v;
+    }
     if (tid < 8 * C::LP) {                            // db2[ch] = sum over pixels of chunk (px * CPT + ch / 8), element ch % 8
       const int part = tid / C::LP, ch = tid - part * C::LP;
       constexpr int PER = (B::NPXC + 7) / 8;

@@ -263,9 +263,9 @@ def test_linearity_of_backward_at_full_size():
 @pytest.mark.parametrize("shape", [(3, 3, 48, 48), (2, 3, 20, 28), (1, 3, 7, 9)])
 def test_saved_image_weight_gradients_equal_recompute_path(shape, monkeypatch):
     """bf16 / 24 units: the weight-gradient kernels fed by the saved t / dt images (two-block kernels) give the
-    gradients of the recompute kernels: identical MFMA sequences for dW1/dW2/dW3/db1/db3 (bit-equal); db2 is the
-    pixel sum of the bf16-rounded dt image instead of the fp32 accumulators (a bf16-rounding-level difference on
-    the 20 conv2 biases per block and what weight-norm derives from them)."""
+    gradients of the recompute kernels: the same bf16 products, summed over pixel tiles in a different fp32 order
+    (3 partial sums per e-tile instead of 2); db2 is the pixel sum of the bf16-rounded dt image instead of the
+    fp32 accumulators (a bf16-rounding-level difference on the 20 conv2 biases per block)."""
     torch.manual_seed(5)
     m = _model(_ns(num_blocks=4, hot_dtype="bf16")).train()
     with torch.no_grad():
@@ -285,4 +285,4 @@ def test_saved_image_weight_gradients_equal_recompute_path(shape, monkeypatch):
     scale = float(g_rec.abs().max())
     assert scale > 0 and torch.isfinite(g_saved).all()
     assert float((g_saved - g_rec).abs().max()) <= 2e-3 * scale
-    assert float((g_saved != g_rec).float().mean()) < 0.02      # only the db2-derived entries may differ at all
+    assert float((g_saved - g_rec).abs().mean()) <= 2e-6 * scale
