@@ -219,6 +219,9 @@ int sr_probe_launch_floor(void* out, int gx, int gy, int threads, int lds_bytes,
 /* The same chain captured in a hipGraph and replayed `iters` times (synchronous; result in *us_per_launch). */
 int sr_probe_launch_floor_graph(void* out, int gx, int gy, int threads, int lds_bytes, int reps, int iters,
                                 float* us_per_launch);
+/* Debug: instrumented kernels (currently sr_tail_wgrad) write s_memrealtime stamps to buf[workgroup][32]
+ * (u64) while the pointer is set; NULL switches it off.  Synchronous. */
+int sr_debug_set_stamps(void* buf);
 
 #ifdef __cplusplus
 }

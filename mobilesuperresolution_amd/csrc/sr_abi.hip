@@ -694,3 +694,9 @@ extern "C" int sr_probe_launch_floor_graph(void* out, int gx, int gy, int thread
   hipStreamDestroy(s);
   return rc;
 }
+
+// debug: route in-kernel time stamps of the instrumented kernels to `buf` ([workgroup][32] u64; NULL = off)
+extern "C" int sr_debug_set_stamps(void* buf) {
+  unsigned long long* p = (unsigned long long*)buf;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_sr_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -3;
+}

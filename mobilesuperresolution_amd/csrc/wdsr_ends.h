@@ -39,62 +39,83 @@ template <typename T> SR_DEV typename FragOf<T>::type lds_chunk_half(const T* im
   return f;
 }
 
+// Staging helpers.  Every helper issues the global loads of up to SR_STAGE_BATCH iterations before the first
+// LDS store of the batch, so a tile costs a couple of HBM round trips instead of one per iteration.
+#define SR_STAGE_BATCH 4
+
 template <typename T, typename E, int P, int NTHREADS = 256>
 SR_DEV void stage_img(T* XI, const float* __restrict__ ximg, float mean, int H, int W, int ty0, int tx0, int tid) {
   typedef typename FragOf<T>::half_type HalfT;
   typedef typename E::template Img<P> I;
   const size_t plane = (size_t)H * W;
-  for (int ip = tid; ip < I::NPI + 8; ip += NTHREADS) {
-    HalfT v;
-    v[0] = (T)0.f; v[1] = (T)0.f; v[2] = (T)0.f; v[3] = (T)1.f;
-    if (ip < I::NPI) {
-      const int iy = ip / I::IW, ix = ip - iy * I::IW;
-      const int Y = ty0 - P + iy, X = tx0 - P + ix;
-      if (Y >= 0 && Y < H && X >= 0 && X < W) {
-        const size_t o = (size_t)Y * W + X;
-        v[0] = (T)(ximg[o] - mean);
-        v[1] = (T)(ximg[plane + o] - mean);
-        v[2] = (T)(ximg[2 * plane + o] - mean);
+  constexpr int TOTAL = I::NPI + 8, ITER = (TOTAL + NTHREADS - 1) / NTHREADS;
+#pragma unroll
+  for (int b0 = 0; b0 < ITER; b0 += SR_STAGE_BATCH) {
+    float v[SR_STAGE_BATCH][3];
+#pragma unroll
+    for (int b = 0; b < SR_STAGE_BATCH; ++b) {
+      const int ip = tid + (b0 + b) * NTHREADS;
+      v[b][0] = 0.f; v[b][1] = 0.f; v[b][2] = 0.f;
+      if (b0 + b < ITER && ip < I::NPI) {
+        const int iy = ip / I::IW, ix = ip - iy * I::IW;
+        const int Y = ty0 - P + iy, X = tx0 - P + ix;
+        if (Y >= 0 && Y < H && X >= 0 && X < W) {
+          const size_t o = (size_t)Y * W + X;
+          v[b][0] = ximg[o] - mean;
+          v[b][1] = ximg[plane + o] - mean;
+          v[b][2] = ximg[2 * plane + o] - mean;
+        }
       }
     }
-    *reinterpret_cast<HalfT*>(XI + ip * 4) = v;
+#pragma unroll
+    for (int b = 0; b < SR_STAGE_BATCH; ++b) {
+      const int ip = tid + (b0 + b) * NTHREADS;
+      if (b0 + b < ITER && ip < TOTAL) {
+        HalfT h;
+        h[0] = (T)v[b][0]; h[1] = (T)v[b][1]; h[2] = (T)v[b][2]; h[3] = (T)1.f;
+        *reinterpret_cast<HalfT*>(XI + ip * 4) = h;
+      }
+    }
+  }
+}
+
+// rows p < NLIVE of a [NROWS][CH] LDS image = pixels (y0 + p / RW, x0 + p % RW) of an NHWC tensor, zero elsewhere
+template <typename T, int CH, int RW, int NROWS, int NLIVE, int NTHREADS>
+SR_DEV void stage_rows(T* dst, const T* __restrict__ src, int H, int W, int y0, int x0, int tid) {
+  typedef typename FragOf<T>::type FragT;
+  constexpr int NC = CH / 8, TOTAL = NROWS * NC, ITER = (TOTAL + NTHREADS - 1) / NTHREADS;
+#pragma unroll
+  for (int b0 = 0; b0 < ITER; b0 += SR_STAGE_BATCH) {
+    FragT v[SR_STAGE_BATCH];
+#pragma unroll
+    for (int b = 0; b < SR_STAGE_BATCH; ++b) {
+      const int idx = tid + (b0 + b) * NTHREADS;
+      const int p = idx / NC, c = idx - p * NC;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[b][j] = (T)0.f;
+      if (b0 + b < ITER && p < NLIVE) {
+        const int py = p / RW, px = p - py * RW;
+        const int Y = y0 + py, X = x0 + px;
+        if (Y >= 0 && Y < H && X >= 0 && X < W) v[b] = *reinterpret_cast<const FragT*>(src + ((size_t)Y * W + X) * CH + c * 8);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < SR_STAGE_BATCH; ++b) {
+      const int idx = tid + (b0 + b) * NTHREADS;
+      if (b0 + b < ITER && idx < TOTAL) *reinterpret_cast<FragT*>(dst + idx * 8) = v[b];
+    }
   }
 }
 
 // feature / gradient tile with a 1-pixel halo: [NPXH_PAD + 2][CH] (CH multiple of 8), zero outside
 template <typename T, typename E, int CH, int NTHREADS = 256>
 SR_DEV void stage_halo(T* dst, const T* __restrict__ src, int H, int W, int ty0, int tx0, int tid) {
-  typedef typename FragOf<T>::type FragT;
-  constexpr int NC = CH / 8;
-  for (int idx = tid; idx < (E::NPXH_PAD + 2) * NC; idx += NTHREADS) {
-    const int hp = idx / NC, c = idx - hp * NC;
-    FragT v;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (T)0.f;
-    if (hp < E::NPXH) {
-      const int hy = hp / E::HW, hx = hp - hy * E::HW;
-      const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
-      if (Y >= 0 && Y < H && X >= 0 && X < W) v = *reinterpret_cast<const FragT*>(src + ((size_t)Y * W + X) * CH + c * 8);
-    }
-    *reinterpret_cast<FragT*>(dst + hp * CH + c * 8) = v;
-  }
+  stage_rows<T, CH, E::HW, E::NPXH_PAD + 2, E::NPXH, NTHREADS>(dst, src, H, W, ty0 - 1, tx0 - 1, tid);
 }
 
 template <typename T, typename E, int CH, int NTHREADS = 256>
 SR_DEV void stage_core(T* dst, const T* __restrict__ src, int H, int W, int ty0, int tx0, int tid) {
-  typedef typename FragOf<T>::type FragT;
-  constexpr int NC = CH / 8;
-  for (int idx = tid; idx < (E::NPXC + 2) * NC; idx += NTHREADS) {
-    const int pc = idx / NC, c = idx - pc * NC;
-    FragT v;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (T)0.f;
-    if (pc < E::NPXC) {
-      const int Y = ty0 + pc / E::TW, X = tx0 + pc % E::TW;
-      if (Y < H && X < W) v = *reinterpret_cast<const FragT*>(src + ((size_t)Y * W + X) * CH + c * 8);
-    }
-    *reinterpret_cast<FragT*>(dst + pc * CH + c * 8) = v;
-  }
+  stage_rows<T, CH, E::TW, E::NPXC + 2, E::NPXC, NTHREADS>(dst, src, H, W, ty0, tx0, tid);
 }
 
 // un-shuffle the HR gradient (NCHW fp32, N x 3 x RH x RW) into a dconv tile [px][COP]:
@@ -108,34 +129,48 @@ SR_DEV void stage_dconv(T* DC, const float* __restrict__ dout, int H, int W, int
   constexpr int TWW = HALO ? E::HW : E::TW;
   const size_t hrw = (size_t)W * R, plane = (size_t)H * R * hrw;
   constexpr int ROWS = 3 * R;                       // (colour, sub-row) pairs per pixel
-  for (int idx = tid; idx < NPX * ROWS; idx += NTHREADS) {
-    const int p = idx / ROWS, cr = idx - p * ROWS;
-    const int c = cr / R, si = cr - c * R;
-    float v[R];
+  constexpr int TOTAL = NPX * ROWS, ITER = (TOTAL + NTHREADS - 1) / NTHREADS;
 #pragma unroll
-    for (int j = 0; j < R; ++j) v[j] = 0.f;
-    if (p < NLIVE) {
-      const int py = p / TWW, px = p - py * TWW;
-      const int Y = ty0 - HALO + py, X = tx0 - HALO + px;
-      if (Y >= 0 && Y < H && X >= 0 && X < W) {
-        const float* s = dout + c * plane + ((size_t)Y * R + si) * hrw + (size_t)X * R;
-        if constexpr (R == 4) {
-          const f32x4 q = *reinterpret_cast<const f32x4*>(s);
-          v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
-        } else {
+  for (int b0 = 0; b0 < ITER; b0 += SR_STAGE_BATCH) {
+    float v[SR_STAGE_BATCH][R];
 #pragma unroll
-          for (int j = 0; j < R; ++j) v[j] = s[j];
+    for (int b = 0; b < SR_STAGE_BATCH; ++b) {
+      const int idx = tid + (b0 + b) * NTHREADS;
+      const int p = idx / ROWS, cr = idx - p * ROWS;
+      const int c = cr / R, si = cr - c * R;
+#pragma unroll
+      for (int j = 0; j < R; ++j) v[b][j] = 0.f;
+      if (b0 + b < ITER && p < NLIVE) {
+        const int py = p / TWW, px = p - py * TWW;
+        const int Y = ty0 - HALO + py, X = tx0 - HALO + px;
+        if (Y >= 0 && Y < H && X >= 0 && X < W) {
+          const float* s = dout + c * plane + ((size_t)Y * R + si) * hrw + (size_t)X * R;
+          if constexpr (R == 4) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(s);
+            v[b][0] = q[0]; v[b][1] = q[1]; v[b][2] = q[2]; v[b][3] = q[3];
+          } else {
+#pragma unroll
+            for (int j = 0; j < R; ++j) v[b][j] = s[j];
+          }
         }
       }
     }
-    T* d = DC + p * E::COP + c * R * R + si * R;
-    if constexpr (R == 4) {
-      typename FragOf<T>::half_type hv;
-      hv[0] = (T)v[0]; hv[1] = (T)v[1]; hv[2] = (T)v[2]; hv[3] = (T)v[3];
-      *reinterpret_cast<typename FragOf<T>::half_type*>(d) = hv;
-    } else {
 #pragma unroll
-      for (int j = 0; j < R; ++j) d[j] = (T)v[j];
+    for (int b = 0; b < SR_STAGE_BATCH; ++b) {
+      const int idx = tid + (b0 + b) * NTHREADS;
+      if (b0 + b < ITER && idx < TOTAL) {
+        const int p = idx / ROWS, cr = idx - p * ROWS;
+        const int c = cr / R, si = cr - c * R;
+        T* d = DC + p * E::COP + c * R * R + si * R;
+        if constexpr (R == 4) {
+          typename FragOf<T>::half_type hv;
+          hv[0] = (T)v[b][0]; hv[1] = (T)v[b][1]; hv[2] = (T)v[b][2]; hv[3] = (T)v[b][3];
+          *reinterpret_cast<typename FragOf<T>::half_type*>(d) = hv;
+        } else {
+#pragma unroll
+          for (int j = 0; j < R; ++j) d[j] = (T)v[b][j];
+        }
+      }
     }
   }
   if constexpr (E::COP > E::CO) {                    // zero the padding channels
@@ -311,6 +346,10 @@ __global__ __launch_bounds__(256) void sr_tail_bwd_data_kernel(const float* __re
 // tile the workgroup walks (no cross-wave reduction), pixels contracted through transposed LDS reads.
 // Slab per workgroup: [TAIL_TILES][16][64]; layout in packing.ends_grad_tables.
 // ---------------------------------------------------------------------------------------------
+// debug time stamps (tools/stamp_ends.py): [workgroup][32] s_memrealtime values when the pointer is set
+__device__ unsigned long long* g_sr_stamps = nullptr;
+#define SR_GSTAMP() do { unsigned long long* sp_ = g_sr_stamps; if (sp_ && threadIdx.x == 0 && stamp_i < 32) sp_[(size_t)blockIdx.x * 32 + stamp_i++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+
 template <typename T, int F, int R>
 __global__ __launch_bounds__(896) void sr_tail_wgrad_kernel(const float* __restrict__ dout, const T* __restrict__ feat,
                                                             const float* __restrict__ ximg, float mean,
@@ -332,14 +371,20 @@ __global__ __launch_bounds__(896) void sr_tail_wgrad_kernel(const float* __restr
 #pragma unroll
   for (int i = 0; i < NT; ++i) acc[i] = zero16();
 
+  int stamp_i = 0;
+  SR_GSTAMP();
   for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
     const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
     const int ty0 = (tile / tiles_x) * E::TH, tx0 = (tile % tiles_x) * E::TW;
     __syncthreads();
+    SR_GSTAMP();
     stage_dconv<T, E, 0, NTHREADS>(DC, dout + (size_t)n * 3 * H * R * W * R, H, W, ty0, tx0, tid);
+    SR_GSTAMP();
     stage_halo<T, E, F, NTHREADS>(FT, feat + (size_t)n * H * W * F, H, W, ty0, tx0, tid);
     stage_img<T, E, 2, NTHREADS>(XI, ximg + (size_t)n * 3 * H * W, mean, H, W, ty0, tx0, tid);
+    SR_GSTAMP();
     __syncthreads();
+    SR_GSTAMP();
     constexpr int UNR = sizeof(T) == 2 ? 3 : 1;
 #pragma unroll UNR
     for (int ot = 0; ot < E::NPT_O; ++ot) {
@@ -357,6 +402,7 @@ __global__ __launch_bounds__(896) void sr_tail_wgrad_kernel(const float* __restr
       }
     }
   }
+  SR_GSTAMP();
   // global tile index: taps (ty*3 + tx)*NT + ti ; skip rows 9*NT + ky*NT + ti
   float* out = partial + (size_t)blockIdx.x * E::TAIL_TILES * 1024;
   const int gbase = is_tap ? (ty * 3 + tx) * NT : (9 + ty) * NT;
@@ -364,6 +410,7 @@ __global__ __launch_bounds__(896) void sr_tail_wgrad_kernel(const float* __restr
   for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
     for (int i = 0; i < 16; ++i) out[((gbase + ti) * 16 + i) * 64 + lane] = acc[ti][i];
+  SR_GSTAMP();
 }
 
 // ---------------------------------------------------------------------------------------------

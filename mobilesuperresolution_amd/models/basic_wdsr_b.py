@@ -59,7 +59,9 @@ class _DeviceState:
         self.blob_body = torch.empty((lay.NB, lay.idx_body.size), dtype=dt, device=device)
         self.cinit_body = torch.empty((lay.NB, lay.idx_cinit.size), dtype=torch.float32, device=device)
         self.blob_tail = torch.empty(lay.idx_tail.size, dtype=dt, device=device)
-        self.wgs_body, self.wgs_tail, self.wgs_head = model.wgs_body, 64, 64
+        self.wgs_body = model.wgs_body
+        self.wgs_tail = int(os.environ.get("SR_WGS_TAIL", 128))
+        self.wgs_head = int(os.environ.get("SR_WGS_HEAD", 128))
         self.part_a = f32(lay.NB * self.wgs_body * lay.slab_a)
         self.part_b = f32(lay.NB * self.wgs_body * lay.slab_b)
         self.part_tail = f32(self.wgs_tail * lay.slab_tail)
