@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="wrap in DistributedDataParallel even with one rank (measures the DDP/RCCL overhead on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -109,8 +111,12 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_ddp = world > 1 or args.force_ddp
+    if use_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", init_method="env://")        # nccl == RCCL on ROCm
 
     from mobilesuperresolution_amd import hotpath as HP
@@ -119,7 +125,7 @@ def main():
     torch.manual_seed(0)                                # identical replicas (DDP broadcasts rank 0 anyway)
     model = get_model(model_ns(args.dtype)).to(dev).train()
     net = model
-    if world > 1:
+    if use_ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
                                                         gradient_as_bucket_view=True, broadcast_buffers=False)
     lr_rate = 1e-3 * world                              # pretrain.py:216 linear scaling
@@ -140,7 +146,7 @@ def main():
         return loss
 
     def sync():
-        if world > 1:
+        if use_ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -238,7 +244,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"WDSR-B x{SCALE}, {BLOCKS} blocks / {UNITS} units, {LR}x{LR} LR patches, "
-                                   f"batch {BATCH} per GPU, fwd+L1+bwd+Adam" + (", DDP/RCCL" if world > 1 else ""),
+                                   f"batch {BATCH} per GPU, fwd+L1+bwd+Adam" + (", DDP/RCCL" if use_ddp else ""),
                        "global_batch": BATCH * world, "parallelism": f"dp{world}"},
             "forward_only_HR_Mpix_s": round(BATCH * HR_MPIX_PER_PATCH * args.steps / fwd_elapsed, 2),
             "final_loss": round(final_loss, 5),
@@ -248,7 +254,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if use_ddp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -218,7 +218,7 @@ int sr_probe_copy(const void* src, void* dst, size_t n_bytes, sr_stream_t stream
 int sr_probe_launch_floor(void* out, int gx, int gy, int threads, int lds_bytes, int reps, sr_stream_t stream);
 /* The same chain captured in a hipGraph and replayed `iters` times (synchronous; result in *us_per_launch). */
 int sr_probe_launch_floor_graph(void* out, int gx, int gy, int threads, int lds_bytes, int reps, int iters,
-                                float* us_per_launch);
+                                float* us_per_launch, float* host_us_per_graph /* may be NULL */);
 /* Debug: instrumented kernels (currently sr_tail_wgrad) write s_memrealtime stamps to buf[workgroup][32]
  * (u64) while the pointer is set; NULL switches it off.  Synchronous. */
 int sr_debug_set_stamps(void* buf);

@@ -23,7 +23,7 @@ SIGNATURES = {
     "sr_wdsr_block2_bwd_data": ([_P] * 11 + [_I] * 5 + [_P], _I),
     "sr_wdsr_block2_fwd_repeat": ([_P] * 7 + [_I] * 6 + [_P], _I),
     "sr_probe_launch_floor": ([_P, _I, _I, _I, _I, _I, _P], _I),
-    "sr_probe_launch_floor_graph": ([_P, _I, _I, _I, _I, _I, _I, _P], _I),
+    "sr_probe_launch_floor_graph": ([_P, _I, _I, _I, _I, _I, _I, _P, _P], _I),
     "sr_debug_set_stamps": ([_P], _I),
     "sr_wdsr_block_fwd_stamps": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P], _I),
     "sr_wdsr_block_fwd_repeat": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),

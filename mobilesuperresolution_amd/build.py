@@ -40,6 +40,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         hipcc = "hipcc"
     cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-Rpass-analysis=kernel-resource-usage", "-I", os.path.join(HERE, "..", "include")]
+    cmd += os.environ.get("SR_EXTRA_HIPCC_FLAGS", "").split()       # experiments only (e.g. -DSR_EXP_...)
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

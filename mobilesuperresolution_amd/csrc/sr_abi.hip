@@ -1,5 +1,6 @@
 // C-ABI entry points of libsr_hotpath.so (declared in include/sr_hotpath.h).
 #include <algorithm>
+#include <cstdlib>
 #include "../../include/sr_hotpath.h"
 #include "wdsr_block.h"
 #include "wdsr_ends.h"
@@ -655,7 +656,7 @@ extern "C" int sr_probe_launch_floor(void* out, int gx, int gy, int threads, int
 // same chain captured once in a hipGraph and replayed: separates the host's launch rate from the GPU's
 // dependent-dispatch cost.  Synchronises; returns microseconds per kernel in *us_per_launch.
 extern "C" int sr_probe_launch_floor_graph(void* out, int gx, int gy, int threads, int lds_bytes, int reps, int iters,
-                                           float* us_per_launch) {
+                                           float* us_per_launch, float* host_us_per_graph) {
   if (!out || !us_per_launch || gx <= 0 || gy <= 0 || threads <= 0 || threads > 1024 || lds_bytes < 4 ||
       lds_bytes > 160 * 1024 || reps <= 0 || iters <= 0)
     return -2;
@@ -677,12 +678,16 @@ extern "C" int sr_probe_launch_floor_graph(void* out, int gx, int gy, int thread
         hipGraphLaunch(ge, s);
         hipStreamSynchronize(s);
         hipEventRecord(e0, s);
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
         for (int i = 0; i < iters; ++i) hipGraphLaunch(ge, s);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
         hipEventRecord(e1, s);
         hipStreamSynchronize(s);
         float ms = 0.f;
         hipEventElapsedTime(&ms, e0, e1);
         *us_per_launch = ms * 1e3f / ((float)reps * iters);
+        if (host_us_per_graph) *host_us_per_graph = (float)(((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) * 1e-3 / iters);
         hipEventDestroy(e0);
         hipEventDestroy(e1);
         hipGraphExecDestroy(ge);

@@ -126,6 +126,9 @@ template <typename T> struct WSrc<T, true> {
   const T* p;
   SR_DEV void tile() {}
   SR_DEV typename FragOf<T>::type get(int idx, int lane) const {
+#ifdef SR_EXP_NO_WEIGHT_READS   // timing experiment only (wrong results): how much of a phase is LDS weight traffic
+    idx = 0;
+#endif
     return *reinterpret_cast<const typename FragOf<T>::type*>(p + (idx * 64 + lane) * 8);
   }
 };

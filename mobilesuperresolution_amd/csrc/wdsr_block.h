@@ -1300,3 +1300,4 @@ __global__ __launch_bounds__((64 * WgradSavedCfg<F, E, L, ROLE>::NWAVES)) void w
     slab_store_tile(out, wave, accA, lane);
   }
 }
+

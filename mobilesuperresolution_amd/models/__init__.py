@@ -7,9 +7,10 @@ import argparse
 
 from .basic_wdsr_b import BASIC_MODEL
 from .basicvsr_arch import ConvResidualBlocks, ResidualBlockNoBN
+from .spynet_arch import flow_warp
 from .wdsr_b import NAS_MODEL, ModelOutput
 
-__all__ = ["BASIC_MODEL", "NAS_MODEL", "ModelOutput", "ConvResidualBlocks", "ResidualBlockNoBN", "get_model",
+__all__ = ["BASIC_MODEL", "NAS_MODEL", "ModelOutput", "ConvResidualBlocks", "ResidualBlockNoBN", "flow_warp", "get_model",
            "update_argparser"]
 
 _REGISTRY = {"BASIC_MODEL": BASIC_MODEL, "NAS_MODEL": NAS_MODEL}

@@ -1,0 +1,105 @@
+"""Measure the other SURVEY 8 rows on one MI355X (numbers quoted in DESIGN.md; bench.py stays the C2 line):
+C2 in fp32 parity mode, C3 (32 units), C4 (BasicVSR propagation over 5-frame 64x64 clips, given flows), C5 (NAS
+supernet step), flow_warp alone, block-forward kernels over a batch sweep.  Prints one JSON object."""
+import argparse, json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as B
+from mobilesuperresolution_amd import _lib as L
+from mobilesuperresolution_amd.models import get_model, ConvResidualBlocks, flow_warp
+from mobilesuperresolution_amd.models.basicvsr_arch import propagate
+
+dev = torch.device("cuda", 0)
+
+
+def timeit(fn, n=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def sr_step(ns, batch, lr=48):
+    torch.manual_seed(0)
+    m = get_model(ns).to(dev).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, fused=True)
+    x = torch.rand(batch, 3, lr, lr, device=dev)
+    hr = torch.rand(batch, 3, lr * ns.scale, lr * ns.scale, device=dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = m(x)
+        out = out[0] if isinstance(out, tuple) else out
+        torch.nn.functional.l1_loss(out, hr).backward()
+        opt.step()
+    t = timeit(step)
+    m.eval()
+    with torch.no_grad():
+        tf = timeit(lambda: m(x))
+    mp = batch * (lr * ns.scale) ** 2 / 1e6
+    return {"train_ms": round(t * 1e3, 4), "train_HR_Mpix_s": round(mp / t, 1), "fwd_ms": round(tf * 1e3, 4),
+            "fwd_HR_Mpix_s": round(mp / tf, 1)}
+
+
+out = {}
+base = dict(model_type="BASIC_MODEL", image_mean=0.5, num_channels=3, scale=4)
+out["C2_bf16"] = sr_step(argparse.Namespace(**base, num_blocks=16, num_residual_units=24, hot_dtype="bf16"), 32)
+out["C2_fp32_parity_mode"] = sr_step(argparse.Namespace(**base, num_blocks=16, num_residual_units=24, hot_dtype="fp32"), 32)
+out["C3_bf16_32units_per_gpu"] = sr_step(argparse.Namespace(**base, num_blocks=16, num_residual_units=32, hot_dtype="bf16"), 32)
+out["C1_shape_batch1_4blocks_bf16"] = sr_step(argparse.Namespace(**base, num_blocks=4, num_residual_units=24, hot_dtype="bf16"), 1)
+nas = argparse.Namespace(model_type="NAS_MODEL", image_mean=0.5, num_channels=3, scale=4, num_blocks=16,
+                         num_residual_units=32, width_search=True, pretrained=False, hot_dtype="bf16")
+try:
+    out["C5_nas_bf16_32units"] = sr_step(nas, 32)
+except Exception as e:                                   # keep the other rows if a ctor flag is missing
+    out["C5_nas_bf16_32units"] = {"error": repr(e)}
+
+# C4: recurrent propagation, 5 frames of 64x64, 24 features, 8 residual blocks per trunk, given flows
+b, n, h, w = 8, 5, 64, 64
+bt = ConvResidualBlocks(27, 24, 8, hot_dtype="bf16").to(dev)
+ft = ConvResidualBlocks(27, 24, 8, hot_dtype="bf16").to(dev)
+clip = torch.rand(b, n, 3, h, w, device=dev)
+fl_f = (torch.rand(b, n - 1, 2, h, w, device=dev) * 4 - 2)
+fl_b = (torch.rand(b, n - 1, 2, h, w, device=dev) * 4 - 2)
+params = list(bt.parameters()) + list(ft.parameters())
+
+
+def vsr_step():
+    for p in params:
+        p.grad = None
+    ob, of = propagate(clip, fl_f, fl_b, bt, ft, flow_warp)
+    (sum(o.sum() for o in ob) + sum(o.sum() for o in of)).backward()
+t = timeit(vsr_step, n=10, warm=3)
+with torch.no_grad():
+    tf = timeit(lambda: propagate(clip, fl_f, fl_b, bt, ft, flow_warp), n=10, warm=3)
+out["C4_vsr_propagation_bf16"] = {"clips": b, "frames": n, "train_ms": round(t * 1e3, 3), "fwd_ms": round(tf * 1e3, 3),
+                                  "LR_frames_per_s_fwd": round(b * n / tf, 1)}
+feat = torch.rand(32, 24, 64, 64, device=dev)
+flow = torch.rand(32, 64, 64, 2, device=dev) * 4 - 2
+with torch.no_grad():
+    tw = timeit(lambda: flow_warp(feat, flow))
+out["flow_warp_32x24x64x64_fp32"] = {"us": round(tw * 1e6, 1), "GB_s_algorithmic": round((2 * feat.numel() * 4 + flow.numel() * 4) / tw / 1e9, 1)}
+
+# block-forward kernels over a batch sweep (bf16, F = 24): how far the kernel itself is from the HBM roof
+m = get_model(B.model_ns("bf16")).to(dev)
+st = m._state(dev)
+sweep = {}
+for batch in (32, 64, 128, 256, 512):
+    a = torch.randn(batch, 48, 48, 24, device=dev).bfloat16()
+    bb, c = torch.empty_like(a), torch.empty_like(a)
+    reps = 64
+    f1 = lambda: L.check(L.lib().sr_wdsr_block_fwd_repeat(a.data_ptr(), bb.data_ptr(), st.blob_body[0].data_ptr(),
+                         st.cinit_body[0].data_ptr(), batch, 48, 48, 24, 1, reps, L.stream_ptr()), "r1")
+    f2 = lambda: L.check(L.lib().sr_wdsr_block2_fwd_repeat(a.data_ptr(), bb.data_ptr(), c.data_ptr(), st.blob_body[0].data_ptr(),
+                         st.blob_body[1].data_ptr(), st.cinit_body[0].data_ptr(), st.cinit_body[1].data_ptr(), batch, 48, 48,
+                         24, 1, reps, L.stream_ptr()), "r2")
+    u1, u2 = timeit(f1, 5, 2) / reps, timeit(f2, 5, 2) / reps
+    alg = 2 * batch * 48 * 48 * 24 * 2
+    sweep[str(batch)] = {"single_us": round(u1 * 1e6, 2), "single_GB_s": round(alg / u1 / 1e9), "pair_us": round(u2 * 1e6, 2),
+                         "pair_GB_s": round(2 * alg / u2 / 1e9)}
+out["block_fwd_batch_sweep_bf16"] = sweep
+print(json.dumps(out))

@@ -14,7 +14,9 @@ for (gx, gy, thr, lds) in [(8, 32, 64, 4), (8, 32, 768, 65536), (8, 32, 896, 147
     e0.record(); run(); e1.record(); torch.cuda.synchronize()
     print(f"grid {gx}x{gy} threads {thr} lds {lds}: {e0.elapsed_time(e1) * 1e3 / reps:.2f} us per launch")
 import ctypes
-res = ctypes.c_float(0)
-for (gx, gy, thr, lds) in [(8, 32, 64, 4), (8, 32, 896, 147456), (8, 32, 768, 65536)]:
-    L.check(L.lib().sr_probe_launch_floor_graph(out.data_ptr(), gx, gy, thr, lds, 100, 10, ctypes.addressof(res)), "graph")
-    print(f"hipGraph: grid {gx}x{gy} threads {thr} lds {lds}: {res.value:.2f} us per launch")
+res, host = ctypes.c_float(0), ctypes.c_float(0)
+for (gx, gy, thr, lds, reps) in [(8, 32, 64, 4, 100), (8, 32, 896, 147456, 100), (8, 32, 896, 147456, 12)]:
+    L.check(L.lib().sr_probe_launch_floor_graph(out.data_ptr(), gx, gy, thr, lds, reps, 20, ctypes.addressof(res),
+                                                ctypes.addressof(host)), "graph")
+    print(f"hipGraph of {reps} kernels: grid {gx}x{gy} threads {thr} lds {lds}: {res.value:.2f} us per kernel on the GPU, "
+          f"{host.value:.1f} us of host time per graph launch")
