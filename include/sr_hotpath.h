@@ -140,6 +140,19 @@ int sr_c3_bwd_data(const void* dA, const void* A, const void* add, void* dx, con
 int sr_c3_wgrad(const void* x, const void* dA, const void* A, float* partial, int wgs, int N, int H, int W,
                 int CI, int act, int dtype, sr_stream_t stream);
 
+/* The whole propagation trunk, ConvResidualBlocks.forward (models/basicvsr_arch.py:108-147), from one call.
+ * x0 [N,H,W,ci0] (ci0 = 32: the 27-channel concat zero-padded, or 24); acts [(nb+1)][N,H,W,24] receives a_0..a_nb
+ * (a_nb = output), mids [nb][N,H,W,24] the post-ReLU conv1 outputs; blob = every conv's packed weights in one
+ * buffer, conv k (0 = first conv, 1+2i / 2+2i = conv1 / conv2 of block i) at ELEMENT offset blob_off[k] (host array). */
+int sr_c3_trunk_fwd(const void* x0, void* acts, void* mids, const void* blob, const long* blob_off, int nb,
+                    int N, int H, int W, int ci0, int dtype, sr_stream_t stream);
+/* Its backward.  ga [(nb+1)][N,H,W,24]: the caller writes d(loss)/d(a_nb) into slot nb, the call fills the other
+ * slots; gt [nb][...] scratch (gradients at the post-ReLU points); parts [(1+2nb)][wgs][9*1024] fp32 weight-gradient
+ * slabs per conv (layout packing.c3_tables "grad"); dx0 (may be NULL) = gradient w.r.t. x0. */
+int sr_c3_trunk_bwd(const void* x0, const void* acts, const void* mids, void* ga, void* gt, const void* blob,
+                    const long* blob_off, float* parts, void* dx0, int nb, int wgs, int N, int H, int W, int ci0,
+                    int dtype, sr_stream_t stream);
+
 /* flow_warp, models/spynet_arch.py:98-129 (bilinear, zeros padding, align_corners=True): x, out NCHW fp32;
  * flow (N,H,W,2).  Backward: dx (zero-filled by the caller, may be NULL) and dflow (may be NULL). */
 int sr_flow_warp_fwd(const float* x, const float* flow, float* out, int N, int C, int H, int W, sr_stream_t stream);

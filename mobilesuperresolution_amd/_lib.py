@@ -25,6 +25,8 @@ SIGNATURES = {
     "sr_probe_launch_floor": ([_P, _I, _I, _I, _I, _I, _P], _I),
     "sr_probe_launch_floor_graph": ([_P, _I, _I, _I, _I, _I, _I, _P, _P], _I),
     "sr_debug_set_stamps": ([_P], _I),
+    "sr_c3_trunk_fwd": ([_P] * 5 + [_I] * 6 + [_P], _I),
+    "sr_c3_trunk_bwd": ([_P] * 9 + [_I] * 7 + [_P], _I),
     "sr_wdsr_block_fwd_stamps": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P], _I),
     "sr_wdsr_block_fwd_repeat": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block_bwd_data": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),

@@ -212,9 +212,13 @@ __global__ __launch_bounds__((64 * C3Cfg::NPT_O)) void c3_bwd_data_kernel(const 
 template <typename T, int CI, int ONES, int ACT>
 __global__ __launch_bounds__((64 * 9)) void c3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dA,
                                                             const T* __restrict__ A, float* __restrict__ partial, int N,
-                                                            int H, int W, int tiles_x, int tiles_per_img) {
+                                                            int H, int W, int tiles_x, int tiles_per_img, long x_ls,
+                                                            long d_ls, long a_ls, long p_ls) {
   typedef C3Cfg C;
   constexpr int NTHREADS = 576;
+  // blockIdx.y = layer: several convolutions of the same kind in one launch (element strides between layers)
+  x += (size_t)blockIdx.y * x_ls; dA += (size_t)blockIdx.y * d_ls; A += (size_t)blockIdx.y * a_ls;
+  partial += (size_t)blockIdx.y * p_ls;
   constexpr int STAGE_BYTES = (C::XC_ELEMS + C::DZ_ELEMS) * (int)sizeof(T);
   constexpr int LDS_BYTES = STAGE_BYTES > 9 * 4096 ? STAGE_BYTES : 9 * 4096;
   __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES];
@@ -247,4 +251,236 @@ __global__ __launch_bounds__((64 * 9)) void c3_wgrad_kernel(const T* __restrict_
   __syncthreads();
   float* out = partial + (size_t)blockIdx.x * 9 * 1024;
   for (int i = tid; i < 9 * 1024; i += NTHREADS) out[i] = slab[i];
+}
+
+// =============================================================================================
+// One ResidualBlockNoBN per launch (bf16): a per-layer launch on a 64x64 clip batch is 144 workgroups of <1 us
+// of work under a ~5 us launch floor, so the two convs of a block share a launch.  conv1 + ReLU runs on the
+// tile + 1-pixel halo from x on a 2-pixel halo and hands t to conv2 through LDS; t is still written once (core)
+// because backward needs it.  Bit-identical to c3_fwd<ReLU> followed by c3_fwd<none, +res>.
+// =============================================================================================
+struct C3Pair {
+  typedef C3Cfg C;
+  static constexpr int W2 = C::TW + 4, H2 = C::TH + 4, NP2 = W2 * H2;       // 28 x 16 = 448
+  static constexpr int NPT_H = C::NPXH_PAD / 32;                             // 12 pixel tiles over the 14x26 region
+  static constexpr int X2_ELEMS = (NP2 + 2) * 32, T1_ELEMS = (C::NPXH_PAD + 2) * 32;
+  static constexpr int G2_ELEMS = (NP2 + 2) * C::CO, M1_ELEMS = (C::NPXH_PAD + 2) * C::CO;
+};
+
+template <typename T>
+__global__ __launch_bounds__((64 * C3Pair::NPT_H)) void c3_resblock_fwd_kernel(const T* __restrict__ x, T* __restrict__ tmid,
+                                                                               T* __restrict__ y, const T* __restrict__ w1,
+                                                                               const T* __restrict__ w2, int H, int W,
+                                                                               int tiles_x) {
+  typedef C3Cfg C;
+  typedef C3Pair P;
+  typedef typename FragOf<T>::type FragT;
+  typedef typename FragOf<T>::half_type HalfT;
+  static_assert(sizeof(T) == 2, "bf16 only (LDS budget)");
+  constexpr int NTHREADS = 64 * P::NPT_H;
+  __shared__ __attribute__((aligned(16))) T smem[P::X2_ELEMS + P::T1_ELEMS + 2 * C::KSF * 512];
+  T* const X2 = smem;
+  T* const T1 = X2 + P::X2_ELEMS;
+  T* const WL = T1 + P::T1_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+  const size_t img = (size_t)n * H * W * C::CO;
+  WSrc<T, true> ws1, ws2;
+  ws1.p = WL;
+  ws2.p = WL + C::KSF * 512;
+  stage_weights<T, NTHREADS>(WL, w1, C::KSF, tid);
+  stage_weights<T, NTHREADS>(WL + C::KSF * 512, w2, C::KSF, tid);
+  {   // x on the 2-pixel halo: [NP2 + 2][32], 24 channels + ones channel at 24
+    constexpr int TOTAL = (P::NP2 + 2) * 4, ITER = (TOTAL + NTHREADS - 1) / NTHREADS;
+    FragT v[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + it * NTHREADS;
+      const int p = idx >> 2, c = idx & 3;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[it][j] = (T)0.f;
+      if (idx < TOTAL && p < P::NP2 && c < 3) {
+        const int py = p / P::W2, px = p - py * P::W2;
+        const int Y = ty0 - 2 + py, X = tx0 - 2 + px;
+        if (Y >= 0 && Y < H && X >= 0 && X < W) v[it] = *reinterpret_cast<const FragT*>(x + img + ((size_t)Y * W + X) * C::CO + c * 8);
+      }
+      if (c == 3) v[it][0] = (T)1.f;
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + it * NTHREADS;
+      if (idx < TOTAL) *reinterpret_cast<FragT*>(X2 + idx * 8) = v[it];
+    }
+    // t image: ones channel and zero padding of every row (conv1 fills the 24 real channels of the live rows)
+    for (int idx = tid; idx < (C::NPXH_PAD + 2) * 4; idx += NTHREADS) {
+      FragT z;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = (T)0.f;
+      if ((idx & 3) == 3) z[0] = (T)1.f;
+      *reinterpret_cast<FragT*>(T1 + idx * 8) = z;
+    }
+  }
+  __syncthreads();
+
+  // ---- conv1 + ReLU on the 14x26 region ----
+  {
+    const int hp1 = wave * 32 + r;
+    const bool live = hp1 < C::NPXH;
+    const int hp1c = live ? hp1 : 0;
+    const int hy = hp1c / C::HW, hx = hp1c - hy * C::HW;
+    const int base2 = hy * P::W2 + hx;
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int s = 0; s < C::KSF; ++s) {
+      const int q = 2 * s + hh, tap = q >> 2, c = q & 3;
+      acc = mma16<T>(ws1.get(s, lane), lds_chunk<T>(X2, (base2 + (tap / 3) * P::W2 + (tap % 3)) * 32 + c * 8), acc);
+    }
+    if (live) {
+      const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
+      const bool inimg = (Y >= 0 && Y < H && X >= 0 && X < W);
+      const bool core = inimg && hy >= 1 && hy <= C::TH && hx >= 1 && hx <= C::TW;
+#pragma unroll
+      for (int g = 0; g < C::COC; ++g) {
+        HalfT v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = inimg ? (T)c3_act<1>(acc[4 * g + j]) : (T)0.f;
+        *reinterpret_cast<HalfT*>(T1 + hp1 * 32 + g * 8 + hh * 4) = v;
+        if (core) *reinterpret_cast<HalfT*>(tmid + img + ((size_t)Y * W + X) * C::CO + g * 8 + hh * 4) = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- conv2 + residual on the core ----
+  if (wave < C::NPT_O) {
+    const int ot = wave;
+    const int oy = (ot / (C::TW / 8)) * 4 + (r >> 3), ox = (ot % (C::TW / 8)) * 8 + (r & 7);
+    const int hbase = oy * C::HW + ox;
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int s = 0; s < C::KSF; ++s) {
+      const int q = 2 * s + hh, tap = q >> 2, c = q & 3;
+      acc = mma16<T>(ws2.get(s, lane), lds_chunk<T>(T1, (hbase + (tap / 3) * C::HW + (tap % 3)) * 32 + c * 8), acc);
+    }
+    const int Y = ty0 + oy, X = tx0 + ox;
+    if (Y < H && X < W) {
+      const size_t o = img + ((size_t)Y * W + X) * C::CO;
+      const T* xr = X2 + ((oy + 2) * P::W2 + ox + 2) * 32;
+#pragma unroll
+      for (int g = 0; g < C::COC; ++g) {
+        const HalfT rv = *reinterpret_cast<const HalfT*>(xr + g * 8 + hh * 4);
+        HalfT v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (T)(acc[4 * g + j] + (float)rv[j]);
+        *reinterpret_cast<HalfT*>(y + o + g * 8 + hh * 4) = v;
+      }
+    }
+  }
+}
+
+// backward-data of one ResidualBlockNoBN per launch: gt = conv2^T(g) on the tile + 1-pixel halo (written once for
+// the conv1 weight gradient), masked by relu'(t), then ga = conv1^T(.) + g on the core.  Bit-identical to
+// c3_bwd_data<none> followed by c3_bwd_data<ReLU, +add>.
+template <typename T>
+__global__ __launch_bounds__((64 * C3Pair::NPT_H)) void c3_resblock_bwd_data_kernel(
+    const T* __restrict__ g, const T* __restrict__ tmid, T* __restrict__ gt, T* __restrict__ ga, const T* __restrict__ w1,
+    const T* __restrict__ w2, int H, int W, int tiles_x) {
+  typedef C3Cfg C;
+  typedef C3Pair P;
+  typedef typename FragOf<T>::type FragT;
+  typedef typename FragOf<T>::half_type HalfT;
+  static_assert(sizeof(T) == 2, "bf16 only (LDS budget)");
+  constexpr int NTHREADS = 64 * P::NPT_H;
+  __shared__ __attribute__((aligned(16))) T smem[P::G2_ELEMS + 2 * P::M1_ELEMS + 2 * C::KSB * 512];
+  T* const G2 = smem;                       // g on the 2-pixel halo [NP2 + 2][24]
+  T* const M1 = G2 + P::G2_ELEMS;           // t on the 1-pixel halo [NPXH_PAD + 2][24]
+  T* const DZ = M1 + P::M1_ELEMS;           // gt * relu'(t)  [NPXH_PAD + 2][24]
+  T* const WL = DZ + P::M1_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+  const size_t img = (size_t)n * H * W * C::CO;
+  WSrc<T, true> ws1, ws2;
+  ws1.p = WL;
+  ws2.p = WL + C::KSB * 512;
+  stage_weights<T, NTHREADS>(WL, w1 + (size_t)C::KSF * 512, C::KSB, tid);
+  stage_weights<T, NTHREADS>(WL + C::KSB * 512, w2 + (size_t)C::KSF * 512, C::KSB, tid);
+  {
+    RegionRegs<T, NTHREADS, P::W2, P::NP2 + 2, P::NP2, C::COC, C::COC, false> rg;
+    RegionRegs<T, NTHREADS, C::HW, C::NPXH_PAD + 2, C::NPXH, C::COC, C::COC, false> rm;
+    rg.load(g + img, H, W, ty0 - 2, tx0 - 2, tid);
+    rm.load(tmid + img, H, W, ty0 - 1, tx0 - 1, tid);
+    rg.store(G2, tid);
+    rm.store(M1, tid);
+    for (int i = tid; i < (C::NPXH_PAD + 2 - C::NPXH) * C::CO; i += NTHREADS) DZ[C::NPXH * C::CO + i] = (T)0.f;   // slack rows
+  }
+  __syncthreads();
+
+  // ---- gt = conv2^T(g) on the 14x26 region; DZ = gt * relu'(t) ----
+  {
+    const int hp1 = wave * 32 + r;
+    const bool live = hp1 < C::NPXH;
+    const int hp1c = live ? hp1 : 0;
+    const int hy = hp1c / C::HW, hx = hp1c - hy * C::HW;
+    const int base2 = hy * P::W2 + hx;
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int s = 0; s < C::KSB; ++s) {
+      const int q = 2 * s + hh;
+      int off = base2 * C::CO;
+      if (q < 27) {
+        const int u = q / 3, c = q - u * 3;
+        off = (base2 + (u / 3) * P::W2 + (u % 3)) * C::CO + c * 8;
+      }
+      acc = mma16<T>(ws2.get(s, lane), lds_chunk<T>(G2, off), acc);
+    }
+    if (live) {
+      const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
+      const bool inimg = (Y >= 0 && Y < H && X >= 0 && X < W);
+      const bool core = inimg && hy >= 1 && hy <= C::TH && hx >= 1 && hx <= C::TW;
+#pragma unroll
+      for (int gi = 0; gi < C::COC; ++gi) {
+        const HalfT v = acc_group<T>(acc, gi);
+        const HalfT a = *reinterpret_cast<const HalfT*>(M1 + hp1 * C::CO + gi * 8 + hh * 4);
+        HalfT z;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[j] = inimg ? (T)((float)v[j] * c3_dact<1>((float)a[j])) : (T)0.f;
+        *reinterpret_cast<HalfT*>(DZ + hp1 * C::CO + gi * 8 + hh * 4) = z;
+        if (core) *reinterpret_cast<HalfT*>(gt + img + ((size_t)Y * W + X) * C::CO + gi * 8 + hh * 4) = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- ga = conv1^T(DZ) + g on the core ----
+  if (wave < C::NPT_O) {
+    const int ot = wave;
+    const int oy = (ot / (C::TW / 8)) * 4 + (r >> 3), ox = (ot % (C::TW / 8)) * 8 + (r & 7);
+    const int hbase = oy * C::HW + ox;
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int s = 0; s < C::KSB; ++s) {
+      const int q = 2 * s + hh;
+      int off = hbase * C::CO;
+      if (q < 27) {
+        const int u = q / 3, c = q - u * 3;
+        off = (hbase + (u / 3) * C::HW + (u % 3)) * C::CO + c * 8;
+      }
+      acc = mma16<T>(ws1.get(s, lane), lds_chunk<T>(DZ, off), acc);
+    }
+    const int Y = ty0 + oy, X = tx0 + ox;
+    if (Y < H && X < W) {
+      const size_t o = img + ((size_t)Y * W + X) * C::CO;
+      const T* gr = G2 + ((oy + 2) * P::W2 + ox + 2) * C::CO;
+#pragma unroll
+      for (int gi = 0; gi < C::COC; ++gi) {
+        const HalfT a = *reinterpret_cast<const HalfT*>(gr + gi * 8 + hh * 4);
+        HalfT v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (T)(acc[4 * gi + j] + (float)a[j]);
+        *reinterpret_cast<HalfT*>(ga + o + gi * 8 + hh * 4) = v;
+      }
+    }
+  }
 }

@@ -26,17 +26,21 @@ SR_DEV float warp_pos(float g, int size) {
   return ((v + 1.0f) * 0.5f) * (float)(size - 1);
 }
 
-__global__ __launch_bounds__(256) void flow_warp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ flow,
-                                                            float* __restrict__ out, int C, int H, int W) {
-  const int n = blockIdx.y;
+// One wave = 16 consecutive pixels x 4 channel phases (channels phase, phase + 4, ...): 4x the waves of a
+// thread-per-pixel mapping and 4x shorter per-thread load chains; the flow gradient is reduced over the phases
+// with two shuffles.
+__global__ __launch_bounds__(64) void flow_warp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ flow,
+                                                           float* __restrict__ out, int C, int H, int W) {
+  const int n = blockIdx.y, phase = threadIdx.x >> 4;
   const size_t plane = (size_t)H * W;
-  for (int p = blockIdx.x * 256 + threadIdx.x; p < (int)plane; p += gridDim.x * 256) {
+  for (int p = blockIdx.x * 16 + (threadIdx.x & 15); p < (int)plane; p += gridDim.x * 16) {
     const int y = p / W, xx = p - y * W;
     const float2 f = *reinterpret_cast<const float2*>(flow + ((size_t)n * plane + p) * 2);
     const WarpTaps t = warp_taps(warp_pos((float)xx + f.x, W), warp_pos((float)y + f.y, H), H, W);
     const float w00 = (1.f - t.wx) * (1.f - t.wy), w01 = t.wx * (1.f - t.wy), w10 = (1.f - t.wx) * t.wy, w11 = t.wx * t.wy;
     const size_t o00 = (size_t)t.y0 * W + t.x0;
-    for (int c = 0; c < C; ++c) {
+#pragma unroll 8
+    for (int c = phase; c < C; c += 4) {
       const float* xp = x + ((size_t)n * C + c) * plane;
       float v = 0.f;
       if (t.vy0 && t.vx0) v += w00 * xp[o00];
@@ -49,33 +53,42 @@ __global__ __launch_bounds__(256) void flow_warp_fwd_kernel(const float* __restr
 }
 
 // dx must be zero-filled by the caller (scatter-add of the four corners); dflow (N, H, W, 2)
-__global__ __launch_bounds__(256) void flow_warp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ flow,
-                                                            const float* __restrict__ gout, float* __restrict__ dx,
-                                                            float* __restrict__ dflow, int C, int H, int W) {
-  const int n = blockIdx.y;
+__global__ __launch_bounds__(64) void flow_warp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ flow,
+                                                           const float* __restrict__ gout, float* __restrict__ dx,
+                                                           float* __restrict__ dflow, int C, int H, int W) {
+  const int n = blockIdx.y, phase = threadIdx.x >> 4;
   const size_t plane = (size_t)H * W;
-  for (int p = blockIdx.x * 256 + threadIdx.x; p < (int)plane; p += gridDim.x * 256) {
-    const int y = p / W, xx = p - y * W;
-    const float2 f = *reinterpret_cast<const float2*>(flow + ((size_t)n * plane + p) * 2);
+  const int iters = ((int)plane + gridDim.x * 16 - 1) / (gridDim.x * 16);      // uniform trip count: shuffles below
+  for (int it = 0; it < iters; ++it) {
+    const int p = (it * gridDim.x + blockIdx.x) * 16 + (threadIdx.x & 15);
+    const bool live = p < (int)plane;
+    const int pc = live ? p : 0;
+    const int y = pc / W, xx = pc - y * W;
+    const float2 f = *reinterpret_cast<const float2*>(flow + ((size_t)n * plane + pc) * 2);
     const WarpTaps t = warp_taps(warp_pos((float)xx + f.x, W), warp_pos((float)y + f.y, H), H, W);
     const float w00 = (1.f - t.wx) * (1.f - t.wy), w01 = t.wx * (1.f - t.wy), w10 = (1.f - t.wx) * t.wy, w11 = t.wx * t.wy;
     const size_t o00 = (size_t)t.y0 * W + t.x0;
     float gx = 0.f, gy = 0.f;
-    for (int c = 0; c < C; ++c) {
-      const size_t base = ((size_t)n * C + c) * plane;
-      const float g = gout[base + p];
-      const float v00 = (t.vy0 && t.vx0) ? x[base + o00] : 0.f, v01 = (t.vy0 && t.vx1) ? x[base + o00 + 1] : 0.f;
-      const float v10 = (t.vy1 && t.vx0) ? x[base + o00 + W] : 0.f, v11 = (t.vy1 && t.vx1) ? x[base + o00 + W + 1] : 0.f;
-      gx += g * ((v01 - v00) * (1.f - t.wy) + (v11 - v10) * t.wy);
-      gy += g * ((v10 - v00) * (1.f - t.wx) + (v11 - v01) * t.wx);
-      if (dx) {
-        if (t.vy0 && t.vx0) atomicAdd(dx + base + o00, w00 * g);
-        if (t.vy0 && t.vx1) atomicAdd(dx + base + o00 + 1, w01 * g);
-        if (t.vy1 && t.vx0) atomicAdd(dx + base + o00 + W, w10 * g);
-        if (t.vy1 && t.vx1) atomicAdd(dx + base + o00 + W + 1, w11 * g);
+    if (live) {
+#pragma unroll 8
+      for (int c = phase; c < C; c += 4) {
+        const size_t base = ((size_t)n * C + c) * plane;
+        const float g = gout[base + p];
+        const float v00 = (t.vy0 && t.vx0) ? x[base + o00] : 0.f, v01 = (t.vy0 && t.vx1) ? x[base + o00 + 1] : 0.f;
+        const float v10 = (t.vy1 && t.vx0) ? x[base + o00 + W] : 0.f, v11 = (t.vy1 && t.vx1) ? x[base + o00 + W + 1] : 0.f;
+        gx += g * ((v01 - v00) * (1.f - t.wy) + (v11 - v10) * t.wy);
+        gy += g * ((v10 - v00) * (1.f - t.wx) + (v11 - v01) * t.wx);
+        if (dx) {
+          if (t.vy0 && t.vx0) unsafeAtomicAdd(dx + base + o00, w00 * g);
+          if (t.vy0 && t.vx1) unsafeAtomicAdd(dx + base + o00 + 1, w01 * g);
+          if (t.vy1 && t.vx0) unsafeAtomicAdd(dx + base + o00 + W, w10 * g);
+          if (t.vy1 && t.vx1) unsafeAtomicAdd(dx + base + o00 + W + 1, w11 * g);
+        }
       }
     }
-    if (dflow) {
+    gx += __shfl_xor(gx, 16); gx += __shfl_xor(gx, 32);
+    gy += __shfl_xor(gy, 16); gy += __shfl_xor(gy, 32);
+    if (dflow && live && phase == 0) {
       // d(position)/d(flow) = (2 / max(size-1,1)) * ((size-1) / 2): 1 for size > 1, 0 for size == 1
       float2 o;
       o.x = W > 1 ? gx : 0.f;

@@ -319,9 +319,9 @@ int c3_bwd_t(const void* dA, const void* A, const void* add, void* dx, const voi
 }
 template <typename T>
 int c3_wgrad_t(const void* x, const void* dA, const void* A, float* partial, int wgs, int N, int H, int W, int CI, int act,
-               hipStream_t st) {
+               hipStream_t st, int layers = 1, long x_ls = 0, long d_ls = 0, long a_ls = 0, long p_ls = 0) {
   const C3Grid g = c3_grid(N, H, W);
-#define L(CI_, ONES_, ACT_) hipLaunchKernelGGL((c3_wgrad_kernel<T, CI_, ONES_, ACT_>), dim3(wgs), dim3(576), 0, st, (const T*)x, (const T*)dA, (const T*)A, partial, N, H, W, g.tx, g.tpi)
+#define L(CI_, ONES_, ACT_) hipLaunchKernelGGL((c3_wgrad_kernel<T, CI_, ONES_, ACT_>), dim3(wgs, layers), dim3(576), 0, st, (const T*)x, (const T*)dA, (const T*)A, partial, N, H, W, g.tx, g.tpi, x_ls, d_ls, a_ls, p_ls)
   if (CI == 32 && act == 2) L(32, 27, 2);
   else if (CI == 24 && act == 1) L(24, 24, 1);
   else if (CI == 24 && act == 0) L(24, 24, 0);
@@ -353,22 +353,94 @@ extern "C" int sr_c3_wgrad(const void* x, const void* dA, const void* A, float* 
                                 : c3_wgrad_t<float>(x, dA, A, partial, wgs, N, H, W, CI, act, (hipStream_t)stream);
 }
 
+// whole propagation trunk (ConvResidualBlocks.forward, models/basicvsr_arch.py:108-147) from one call
+template <typename T>
+static int c3_trunk_fwd_t(const void* x0, void* acts_, void* mids_, const void* blob_, const long* boff, int nb, int N,
+                          int H, int W, int ci0, hipStream_t st) {
+  const size_t act = (size_t)N * H * W * 24;
+  T* acts = (T*)acts_; T* mids = (T*)mids_; const T* blob = (const T*)blob_;
+  int rc;
+  if ((rc = c3_fwd_t<T>(x0, nullptr, acts, blob + boff[0], N, H, W, ci0, 2, st))) return rc;
+  for (int i = 0; i < nb; ++i) {
+    if constexpr (sizeof(T) == 2) {                    // one launch per residual block
+      const C3Grid g = c3_grid(N, H, W);
+      hipLaunchKernelGGL((c3_resblock_fwd_kernel<T>), g.grid, dim3(64 * C3Pair::NPT_H), 0, st, acts + i * act, mids + i * act,
+                         acts + (i + 1) * act, blob + boff[1 + 2 * i], blob + boff[2 + 2 * i], H, W, g.tx);
+      SR_HIP_CHECK_LAUNCH();
+      continue;
+    }
+    if ((rc = c3_fwd_t<T>(acts + i * act, nullptr, mids + i * act, blob + boff[1 + 2 * i], N, H, W, 24, 1, st))) return rc;
+    if ((rc = c3_fwd_t<T>(mids + i * act, acts + i * act, acts + (i + 1) * act, blob + boff[2 + 2 * i], N, H, W, 24, 0, st)))
+      return rc;
+  }
+  return 0;
+}
+template <typename T>
+static int c3_trunk_bwd_t(const void* x0, const void* acts_, const void* mids_, void* ga_, void* gt_, const void* blob_,
+                          const long* boff, float* parts, void* dx0, int nb, int wgs, int N, int H, int W, int ci0,
+                          hipStream_t st) {
+  const size_t act = (size_t)N * H * W * 24;
+  const T* acts = (const T*)acts_; const T* mids = (const T*)mids_; const T* blob = (const T*)blob_;
+  T* ga = (T*)ga_; T* gt = (T*)gt_;
+  const long slot = (long)wgs * 9 * 1024;
+  int rc;
+  for (int i = nb - 1; i >= 0; --i) {                // a_{i+1} = a_i + conv2(t_i), t_i = relu(conv1(a_i))
+    if constexpr (sizeof(T) == 2) {
+      const C3Grid g = c3_grid(N, H, W);
+      hipLaunchKernelGGL((c3_resblock_bwd_data_kernel<T>), g.grid, dim3(64 * C3Pair::NPT_H), 0, st, ga + (i + 1) * act,
+                         mids + i * act, gt + i * act, ga + i * act, blob + boff[1 + 2 * i], blob + boff[2 + 2 * i], H, W, g.tx);
+      SR_HIP_CHECK_LAUNCH();
+      continue;
+    }
+    if ((rc = c3_bwd_t<T>(ga + (i + 1) * act, ga + (i + 1) * act, nullptr, gt + i * act, blob + boff[2 + 2 * i], N, H, W, 24, 0, st)))
+      return rc;
+    if ((rc = c3_bwd_t<T>(gt + i * act, mids + i * act, ga + (i + 1) * act, ga + i * act, blob + boff[1 + 2 * i], N, H, W, 24, 1, st)))
+      return rc;
+  }
+  if (nb > 0) {                                      // every conv2, then every conv1, one launch each
+    if ((rc = c3_wgrad_t<T>(mids, ga + act, ga + act, parts + 2 * slot, wgs, N, H, W, 24, 0, st, nb, (long)act, (long)act,
+                            (long)act, 2 * slot)))
+      return rc;
+    if ((rc = c3_wgrad_t<T>(acts, gt, mids, parts + slot, wgs, N, H, W, 24, 1, st, nb, (long)act, (long)act, (long)act, 2 * slot)))
+      return rc;
+  }
+  if ((rc = c3_wgrad_t<T>(x0, ga, acts, parts, wgs, N, H, W, ci0, 2, st))) return rc;
+  if (dx0 && (rc = c3_bwd_t<T>(ga, acts, nullptr, dx0, blob + boff[0], N, H, W, ci0, 2, st))) return rc;
+  return 0;
+}
+extern "C" int sr_c3_trunk_fwd(const void* x0, void* acts, void* mids, const void* blob, const long* blob_off, int nb,
+                               int N, int H, int W, int ci0, int dtype, sr_stream_t stream) {
+  if (!x0 || !acts || (nb > 0 && !mids) || !blob || !blob_off || nb < 0 || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
+  return dtype == SR_DTYPE_BF16 ? c3_trunk_fwd_t<__bf16>(x0, acts, mids, blob, blob_off, nb, N, H, W, ci0, (hipStream_t)stream)
+                                : c3_trunk_fwd_t<float>(x0, acts, mids, blob, blob_off, nb, N, H, W, ci0, (hipStream_t)stream);
+}
+extern "C" int sr_c3_trunk_bwd(const void* x0, const void* acts, const void* mids, void* ga, void* gt, const void* blob,
+                               const long* blob_off, float* parts, void* dx0, int nb, int wgs, int N, int H, int W, int ci0,
+                               int dtype, sr_stream_t stream) {
+  if (!x0 || !acts || !ga || (nb > 0 && (!mids || !gt)) || !blob || !blob_off || !parts || nb < 0 || wgs <= 0 || N <= 0 ||
+      H <= 0 || W <= 0 || N > 65535)
+    return -2;
+  return dtype == SR_DTYPE_BF16
+             ? c3_trunk_bwd_t<__bf16>(x0, acts, mids, ga, gt, blob, blob_off, parts, dx0, nb, wgs, N, H, W, ci0, (hipStream_t)stream)
+             : c3_trunk_bwd_t<float>(x0, acts, mids, ga, gt, blob, blob_off, parts, dx0, nb, wgs, N, H, W, ci0, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------------------------------
 // flow_warp
 // ------------------------------------------------------------------------------------------
 extern "C" int sr_flow_warp_fwd(const float* x, const float* flow, float* out, int N, int C, int H, int W,
                                 sr_stream_t stream) {
   if (!x || !flow || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
-  const int blocks = std::min((H * W + 255) / 256, 1024);
-  hipLaunchKernelGGL(flow_warp_fwd_kernel, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, x, flow, out, C, H, W);
+  const int blocks = std::min((H * W + 15) / 16, 8192);          // one wave = 16 pixels x 4 channel phases
+  hipLaunchKernelGGL(flow_warp_fwd_kernel, dim3(blocks, N), dim3(64), 0, (hipStream_t)stream, x, flow, out, C, H, W);
   SR_HIP_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int sr_flow_warp_bwd(const float* x, const float* flow, const float* gout, float* dx, float* dflow, int N,
                                 int C, int H, int W, sr_stream_t stream) {
   if (!x || !flow || !gout || N <= 0 || C <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
-  const int blocks = std::min((H * W + 255) / 256, 1024);
-  hipLaunchKernelGGL(flow_warp_bwd_kernel, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, x, flow, gout, dx, dflow,
+  const int blocks = std::min((H * W + 15) / 16, 8192);
+  hipLaunchKernelGGL(flow_warp_bwd_kernel, dim3(blocks, N), dim3(64), 0, (hipStream_t)stream, x, flow, gout, dx, dflow,
                      C, H, W);
   SR_HIP_CHECK_LAUNCH();
   return 0;

@@ -15,6 +15,7 @@ the trunk; flow_warp itself is the next row of SURVEY 8(f) and is taken as a cal
 from __future__ import annotations
 
 import os
+from collections import OrderedDict
 from functools import lru_cache
 
 import numpy as np
@@ -38,11 +39,37 @@ def _tables(ci_real: int, device_index: int):
 
 
 def _pack(conv: nn.Conv2d, dtype):
+    """one conv's packed weights (per-op entry points / tests)"""
     w = conv.weight
     idx, _, size = _tables(w.shape[1], w.device.index if w.device.index is not None else torch.cuda.current_device())
     src = torch.cat([w.detach().reshape(-1).float(), conv.bias.detach().float(), w.new_tensor([0.0, 1.0])])
     assert src.numel() == size
     return src.index_select(0, idx).to(dtype).contiguous()
+
+
+@lru_cache(maxsize=None)
+def _trunk_tables(cin: int, nb: int, device_index: int):
+    """Combined tables of a whole trunk over the flat parameter (conv k = weight | bias, contiguous, in state_dict
+    order): `blob = cat(flat, [0, 1])[pack_idx]` packs every conv at once (conv k starts at element blob_off[k]);
+    `gflat = slabs.flatten()[grad_idx]` gathers the gradient of the flat parameter."""
+    import ctypes
+    dev = torch.device("cuda", device_index)
+    first, rest = P.c3_tables(cin), P.c3_tables(24)
+    total = (24 * cin * 9 + 24) + 2 * nb * (24 * 24 * 9 + 24)
+    pack, grad, boff, foff, npk = [], [], [], 0, 0
+    for k in range(1 + 2 * nb):
+        t = first if k == 0 else rest
+        nreal = t["off"]["zero"]                               # weight | bias elements of this conv
+        idx = t["w"].astype(np.int64)
+        idx = np.where(idx < nreal, idx + foff, total + (idx - nreal))      # zero / one -> the two appended constants
+        boff.append(npk)
+        npk += len(idx)
+        pack.append(idx)
+        grad.append(t["grad"].astype(np.int64) + k * 9 * 1024)
+        foff += nreal
+    assert foff == total
+    return (torch.from_numpy(np.concatenate(pack)).to(dev), torch.from_numpy(np.concatenate(grad)).to(dev),
+            (ctypes.c_long * len(boff))(*boff), torch.tensor([0.0, 1.0], device=dev))
 
 
 class ResidualBlockNoBN(nn.Module):
@@ -58,6 +85,10 @@ class ResidualBlockNoBN(nn.Module):
 
 
 class ConvResidualBlocks(nn.Module):
+    """One flat fp32 nn.Parameter (`flat`) holds every conv in the reference's state_dict order; `state_dict()` /
+    `load_state_dict()` expose / accept the reference keys (`main.0.weight`, `main.2.{i}.conv1.bias`, ...) as views.
+    The recurrent loops call the trunk once per frame and direction: with per-tensor parameters every call
+    would cost 2 x (1 + 2 n) gradient accumulations in autograd, with the flat buffer it costs one."""
 
     def __init__(self, num_in_ch=3, num_out_ch=64, num_block=15, hot_dtype=None):
         super().__init__()
@@ -67,22 +98,65 @@ class ConvResidualBlocks(nn.Module):
         self.num_in_ch, self.num_feat, self.num_block = num_in_ch, num_out_ch, num_block
         name = hot_dtype or os.environ.get("SR_HOT_DTYPE", "fp32")
         self.hot_dtype = name if isinstance(name, torch.dtype) else _DTYPES[str(name).lower().replace("float32", "fp32").replace("bfloat16", "bf16")]
-        self.main = nn.Sequential(nn.Conv2d(num_in_ch, num_out_ch, 3, 1, 1, bias=True), nn.Identity(),
-                                  nn.Sequential(*[ResidualBlockNoBN(num_feat=num_out_ch) for _ in range(num_block)]))
+        # same constructor calls, in the same order, as the reference (same RNG draws); then flattened
+        main = nn.Sequential(nn.Conv2d(num_in_ch, num_out_ch, 3, 1, 1, bias=True), nn.Identity(),
+                             nn.Sequential(*[ResidualBlockNoBN(num_feat=num_out_ch) for _ in range(num_block)]))
+        self.entries, off, vals = OrderedDict(), 0, []
+        for key, t in main.state_dict(prefix="main.").items():
+            self.entries[key] = (off, tuple(t.shape))
+            vals.append(t.detach().reshape(-1))
+            off += t.numel()
+        self.flat = nn.Parameter(torch.cat(vals).float())
 
-    def _convs(self):
-        out = [self.main[0]]
-        for blk in self.main[2]:
-            out += [blk.conv1, blk.conv2]
-        return out
+    # ---- reference-compatible checkpoints ----
+    def named_tensors(self, source=None):
+        """(reference key, view) over the flat parameter (or any tensor laid out like it, e.g. its gradient)"""
+        base = self.flat.detach() if source is None else source
+        for name, (off, shape) in self.entries.items():
+            yield name, base[off:off + int(np.prod(shape))].view(shape)
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        if destination is None:
+            destination = OrderedDict()
+        for name, view in self.named_tensors():
+            destination[prefix + name] = view
+        return destination
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        with torch.no_grad():
+            for name, view in self.named_tensors():
+                key = prefix + name
+                if key not in state_dict:
+                    missing_keys.append(key)
+                    continue
+                src = state_dict[key]
+                if tuple(src.shape) != tuple(view.shape):
+                    error_msgs.append(f"size mismatch for {key}: checkpoint {tuple(src.shape)} vs model {tuple(view.shape)}")
+                    continue
+                view.copy_(src)
+        for key in state_dict:
+            if key.startswith(prefix) and key[len(prefix):] not in self.entries and key != prefix + "flat":
+                unexpected_keys.append(key)
+
+    def _packed(self, flat):
+        """every conv's MFMA-fragment weights in one buffer; re-packed (3 launches) only when the parameter changed —
+        the recurrent loops call the trunk once per frame and direction with the same weights"""
+        key = (self.hot_dtype, flat.data_ptr(), flat._version)
+        if getattr(self, "_blob_key", None) != key:
+            dev = flat.device
+            tabs = _trunk_tables(self.num_in_ch, self.num_block,
+                                 dev.index if dev.index is not None else torch.cuda.current_device())
+            self._blob = torch.cat([flat.detach(), tabs[3]]).index_select(0, tabs[0]).to(self.hot_dtype)
+            self._blob_key = key
+        return self._blob
 
     def forward(self, fea: torch.Tensor) -> torch.Tensor:
         if not fea.is_cuda:
             raise L.HotpathError("ConvResidualBlocks (MI355X hot path) needs CUDA/HIP tensors; there is no CPU fallback")
         if fea.dim() != 4 or fea.shape[1] != self.num_in_ch:
             raise ValueError(f"expected N x {self.num_in_ch} x H x W input, got {tuple(fea.shape)}")
-        params = [p for c in self._convs() for p in (c.weight, c.bias)]
-        return _TrunkFunction.apply(fea, self, *params)
+        return _TrunkFunction.apply(fea, self, self.flat)
 
 
 def _launch(name, *args):
@@ -90,67 +164,48 @@ def _launch(name, *args):
 
 
 class _TrunkFunction(torch.autograd.Function):
+    """whole trunk forward / backward as one C call each (csrc/conv3x3.h via sr_c3_trunk_fwd / _bwd)"""
 
     @staticmethod
-    def forward(ctx, fea, mod, *params):
+    def forward(ctx, fea, mod, flat):
         dt, nb, cin = mod.hot_dtype, mod.num_block, mod.num_in_ch
-        code = L.DTYPE_CODE[dt]
         n, _, h, w = fea.shape
+        dev = fea.device
         ci0 = 32 if cin == 27 else 24
-        x0 = fea.detach().permute(0, 2, 3, 1)
         if ci0 != cin:
-            x0 = F.pad(x0, (0, ci0 - cin))
-        x0 = x0.to(dt).contiguous()
-        convs = mod._convs()
-        blobs = [_pack(c, dt) for c in convs]
-        acts = torch.empty((nb + 1, n, h, w, 24), dtype=dt, device=fea.device)      # a_0 .. a_nb
-        mids = torch.empty((max(nb, 1), n, h, w, 24), dtype=dt, device=fea.device)  # t_i = relu(conv1(a_i))
-        _launch("sr_c3_fwd", x0.data_ptr(), None, acts[0].data_ptr(), blobs[0].data_ptr(), n, h, w, ci0, 2, code)
-        for i in range(nb):
-            _launch("sr_c3_fwd", acts[i].data_ptr(), None, mids[i].data_ptr(), blobs[1 + 2 * i].data_ptr(), n, h, w, 24, 1, code)
-            _launch("sr_c3_fwd", mids[i].data_ptr(), acts[i].data_ptr(), acts[i + 1].data_ptr(), blobs[2 + 2 * i].data_ptr(),
-                    n, h, w, 24, 0, code)
-        ctx.mod, ctx.x0, ctx.acts, ctx.mids, ctx.blobs = mod, x0, acts, mids, blobs
+            x0 = torch.zeros((n, h, w, ci0), dtype=dt, device=dev)
+            x0[..., :cin] = fea.detach().permute(0, 2, 3, 1)
+        else:
+            x0 = fea.detach().permute(0, 2, 3, 1).to(dt).contiguous()
+        blob = mod._packed(flat)
+        tabs = _trunk_tables(cin, nb, dev.index if dev.index is not None else torch.cuda.current_device())
+        acts = torch.empty((nb + 1, n, h, w, 24), dtype=dt, device=dev)              # a_0 .. a_nb
+        mids = torch.empty((max(nb, 1), n, h, w, 24), dtype=dt, device=dev)          # t_i = relu(conv1(a_i))
+        _launch("sr_c3_trunk_fwd", x0.data_ptr(), acts.data_ptr(), mids.data_ptr(), blob.data_ptr(), tabs[2], nb, n, h, w,
+                ci0, L.DTYPE_CODE[dt])
+        ctx.mod, ctx.x0, ctx.acts, ctx.mids, ctx.blob = mod, x0, acts, mids, blob
         ctx.need_dx = fea.requires_grad
         return acts[nb].permute(0, 3, 1, 2).float().contiguous()
 
     @staticmethod
     def backward(ctx, dy):
-        mod, x0, acts, mids, blobs = ctx.mod, ctx.x0, ctx.acts, ctx.mids, ctx.blobs
+        mod, x0, acts, mids, blob = ctx.mod, ctx.x0, ctx.acts, ctx.mids, ctx.blob
         dt, nb, cin = mod.hot_dtype, mod.num_block, mod.num_in_ch
-        code = L.DTYPE_CODE[dt]
         n, h, w, ci0 = x0.shape
         dev = x0.device
         wgs = 64
-        g = dy.permute(0, 2, 3, 1).to(dt).contiguous()
-        convs = mod._convs()
-        parts = torch.empty((len(convs), wgs, 9 * 1024), dtype=torch.float32, device=dev)
-        dtmp = torch.empty_like(g)
-        for i in range(nb - 1, -1, -1):
-            # a_{i+1} = a_i + conv2(t_i), t_i = relu(conv1(a_i))
-            _launch("sr_c3_wgrad", mids[i].data_ptr(), g.data_ptr(), None, parts[2 + 2 * i].data_ptr(), wgs, n, h, w, 24, 0, code)
-            _launch("sr_c3_bwd_data", g.data_ptr(), None, None, dtmp.data_ptr(), blobs[2 + 2 * i].data_ptr(), n, h, w, 24, 0, code)
-            _launch("sr_c3_wgrad", acts[i].data_ptr(), dtmp.data_ptr(), mids[i].data_ptr(), parts[1 + 2 * i].data_ptr(), wgs,
-                    n, h, w, 24, 1, code)
-            gn = torch.empty_like(g)
-            _launch("sr_c3_bwd_data", dtmp.data_ptr(), mids[i].data_ptr(), g.data_ptr(), gn.data_ptr(),
-                    blobs[1 + 2 * i].data_ptr(), n, h, w, 24, 1, code)
-            g = gn
-        _launch("sr_c3_wgrad", x0.data_ptr(), g.data_ptr(), acts[0].data_ptr(), parts[0].data_ptr(), wgs, n, h, w, ci0, 2, code)
-        dfea = None
-        if ctx.need_dx:
-            dx0 = torch.empty_like(x0)
-            _launch("sr_c3_bwd_data", g.data_ptr(), acts[0].data_ptr(), None, dx0.data_ptr(), blobs[0].data_ptr(), n, h, w,
-                    ci0, 2, code)
-            dfea = dx0[..., :cin].permute(0, 3, 1, 2).float().contiguous()
-        slabs = parts.sum(1)
-        grads = []
-        for k, c in enumerate(convs):
-            _, gidx, _ = _tables(c.weight.shape[1], dev.index if dev.index is not None else torch.cuda.current_device())
-            gv = slabs[k].index_select(0, gidx)
-            nw = c.weight.numel()
-            grads += [gv[:nw].view_as(c.weight), gv[nw:]]
-        return (dfea, None, *grads)
+        _, grad_idx, boff, _ = _trunk_tables(cin, nb, dev.index if dev.index is not None else torch.cuda.current_device())
+        ga = torch.empty_like(acts)                                                  # gradient at a_0 .. a_nb
+        gt = torch.empty_like(mids)
+        ga[nb] = dy.permute(0, 2, 3, 1)
+        parts = torch.empty((1 + 2 * nb, wgs, 9 * 1024), dtype=torch.float32, device=dev)
+        dx0 = torch.empty_like(x0) if ctx.need_dx else None
+        _launch("sr_c3_trunk_bwd", x0.data_ptr(), acts.data_ptr(), mids.data_ptr(), ga.data_ptr(), gt.data_ptr(),
+                blob.data_ptr(), boff, parts.data_ptr(), dx0.data_ptr() if dx0 is not None else None, nb, wgs, n, h, w, ci0,
+                L.DTYPE_CODE[dt])
+        dfea = dx0[..., :cin].permute(0, 3, 1, 2).float().contiguous() if dx0 is not None else None
+        gflat = parts.sum(1).reshape(-1).index_select(0, grad_idx)                   # dW | db of every conv, flat order
+        return dfea, None, gflat
 
 
 def propagate(x, flows_forward, flows_backward, backward_trunk, forward_trunk, flow_warp, num_feat=24):
