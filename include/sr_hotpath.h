@@ -119,6 +119,10 @@ int sr_tail_bwd_data(const float* dout, void* dfeat, const void* wblob, int N, i
  * (packing.ends_grad_tables()["tail"]); NT = ceil(3 R^2 / 32). */
 int sr_tail_wgrad(const float* dout, const void* feat, const float* x_nchw, float mean, float* partial,
                   int wgs, int N, int H, int W, int F, int R, int dtype, sr_stream_t stream);
+/* sr_tail_bwd_data + sr_tail_wgrad in one launch (bf16 only; -1 otherwise): reads the HR gradient once.
+ * Same outputs, bit for bit, as the two calls with the same `wgs`. */
+int sr_tail_bwd(const float* dout, const void* feat, const float* x, float mean, const void* wblob, void* dfeat,
+                float* partial, int wgs, int N, int H, int W, int F, int R, int dtype, sr_stream_t stream);
 /* Weight/bias gradient of the head conv from dy0 = d(loss)/d(head output), NHWC: partial[wgs][3*1024]. */
 int sr_head_wgrad(const void* dy0, const float* x_nchw, float mean, float* partial, int wgs,
                   int N, int H, int W, int F, int dtype, sr_stream_t stream);

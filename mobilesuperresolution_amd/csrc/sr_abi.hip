@@ -264,6 +264,21 @@ extern "C" int sr_tail_wgrad(const float* dout, const void* feat, const float* x
   return 0;
 }
 
+extern "C" int sr_tail_bwd(const float* dout, const void* feat, const float* x, float mean, const void* wblob,
+                          void* dfeat, float* partial, int wgs, int N, int H, int W, int F, int R, int dtype,
+                          sr_stream_t stream) {
+  if (!dout || !feat || !x || !wblob || !dfeat || !partial || wgs <= 0 || N <= 0 || H <= 0 || W <= 0) return -2;
+  if (dtype != SR_DTYPE_BF16) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  typedef __bf16 TB;
+#define CALLR(T, F_, R_) { typedef EndsCfg<F_, R_> E; const int tx = (W + E::TW - 1) / E::TW, tpi = tx * ((H + E::TH - 1) / E::TH); \
+    hipLaunchKernelGGL((sr_tail_bwd_kernel<T, F_, R_>), dim3(wgs), dim3(896), 0, st, dout, (const T*)feat, x, mean, (const T*)wblob, (T*)dfeat, partial, N, H, W, tx, tpi); }
+  if (F == 24) { SR_DISPATCH_R(CALLR, TB, 24) } else if (F == 32) { SR_DISPATCH_R(CALLR, TB, 32) } else return -1;
+#undef CALLR
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int sr_head_wgrad(const void* dy0, const float* x, float mean, float* partial, int wgs, int N, int H,
                              int W, int F, int dtype, sr_stream_t stream) {
   if (!dy0 || !x || !partial || wgs <= 0 || N <= 0 || H <= 0 || W <= 0) return -2;
@@ -587,12 +602,18 @@ extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) 
   char* acts = (char*)n->acts;
   char* grads = (char*)n->grads;
   int rc;
-  if ((rc = sr_tail_bwd_data(n->dout, grads + (size_t)n->NB * act, n->blob_tail, n->N, n->H, n->W, n->F, n->R,
-                             n->dtype, stream)))
-    return rc;
-  if ((rc = sr_tail_wgrad(n->dout, acts + (size_t)n->NB * act, n->x, n->mean, n->part_tail, n->wgs_tail, n->N, n->H,
-                          n->W, n->F, n->R, n->dtype, stream)))
-    return rc;
+  if (n->dtype == SR_DTYPE_BF16) {                  // data + weight gradients of the tail in one launch
+    if ((rc = sr_tail_bwd(n->dout, acts + (size_t)n->NB * act, n->x, n->mean, n->blob_tail, grads + (size_t)n->NB * act,
+                          n->part_tail, n->wgs_tail, n->N, n->H, n->W, n->F, n->R, n->dtype, stream)))
+      return rc;
+  } else {
+    if ((rc = sr_tail_bwd_data(n->dout, grads + (size_t)n->NB * act, n->blob_tail, n->N, n->H, n->W, n->F, n->R,
+                               n->dtype, stream)))
+      return rc;
+    if ((rc = sr_tail_wgrad(n->dout, acts + (size_t)n->NB * act, n->x, n->mean, n->part_tail, n->wgs_tail, n->N, n->H,
+                            n->W, n->F, n->R, n->dtype, stream)))
+      return rc;
+  }
   const bool pairs = n->F == 24 && n->dtype == SR_DTYPE_BF16;   // two blocks per launch
   const bool saved = net_saves_side_images(n, true);
   const size_t side = side_image_bytes(n);

@@ -463,3 +463,94 @@ __global__ __launch_bounds__(576) void sr_head_wgrad_kernel(const T* __restrict_
     out[i] = slab[(3 * k) * 1024 + w] + slab[(3 * k + 1) * 1024 + w] + slab[(3 * k + 2) * 1024 + w];
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// tail backward, data and weight gradients in one launch (bf16): both stage the same un-shuffled HR gradient
+// tile (14 MB of fp32 per batch), so the fused kernel reads it once and drops a dependent launch.  Per tile
+// waves 0..8 first compute dfeat for one 32-pixel tile each (weights staged once per workgroup in LDS), then all
+// 14 waves accumulate their weight-gradient tiles as sr_tail_wgrad_kernel does (no barrier in between: both
+// only read LDS).  Bit-identical to sr_tail_bwd_data_kernel + sr_tail_wgrad_kernel with the same grid.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int F, int R>
+__global__ __launch_bounds__(896) void sr_tail_bwd_kernel(const float* __restrict__ dout, const T* __restrict__ feat,
+                                                          const float* __restrict__ ximg, float mean,
+                                                          const T* __restrict__ wblob, T* __restrict__ dfeat,
+                                                          float* __restrict__ partial, int N, int H, int W, int tiles_x,
+                                                          int tiles_per_img) {
+  typedef EndsCfg<F, R> E;
+  typedef typename E::template Img<2> I;
+  typedef typename FragOf<T>::type FragT;
+  typedef typename FragOf<T>::half_type HalfT;
+  static_assert(sizeof(T) == 2, "bf16 only");
+  constexpr int NT = E::NT, NTHREADS = 896;
+  __shared__ __attribute__((aligned(16))) T smem[E::DC_ELEMS + E::FT_ELEMS + I::ELEMS + E::KSTB * 512];
+  T* const DC = smem;                       // dconv with halo [NPXH_PAD + 2][COP]
+  T* const FT = DC + E::DC_ELEMS;
+  T* const XI = FT + E::FT_ELEMS;
+  T* const WL = XI + I::ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const bool is_tap = wave < 9;
+  const int ty = is_tap ? wave / 3 : wave - 9, tx = is_tap ? wave % 3 : 0;
+  stage_weights<T, NTHREADS>(WL, wblob + (size_t)E::NT * E::KST * 512, E::KSTB, tid);   // backward-data section
+  WSrc<T, true> wsrc;
+  wsrc.p = WL;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = zero16();
+
+  for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
+    const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
+    const int ty0 = (tile / tiles_x) * E::TH, tx0 = (tile % tiles_x) * E::TW;
+    __syncthreads();
+    stage_dconv<T, E, 1, NTHREADS>(DC, dout + (size_t)n * 3 * H * R * W * R, H, W, ty0, tx0, tid);
+    stage_halo<T, E, F, NTHREADS>(FT, feat + (size_t)n * H * W * F, H, W, ty0, tx0, tid);
+    stage_img<T, E, 2, NTHREADS>(XI, ximg + (size_t)n * 3 * H * W, mean, H, W, ty0, tx0, tid);
+    __syncthreads();
+    if (wave < E::NPT_O) {                  // dfeat[px, f] = sum_{u, ch} Wt[ch, f, 8-u] dconv[px + u - 1, ch]
+      const int ot = wave;
+      const int oy = (ot / (E::TW / 8)) * 4 + (r >> 3), ox = (ot % (E::TW / 8)) * 8 + (r & 7);
+      const int hbase = oy * E::HW + ox;
+      f32x16 d = zero16();
+      constexpr int UNRD = (NT > 1 && F > 24) ? 3 : E::KSTB;      // x4 / 32 units: keep the operand prefetch short
+#pragma unroll UNRD
+      for (int s = 0; s < E::KSTB; ++s) {
+        const int q = 2 * s + hh;
+        int off = hbase * E::COP;
+        if (q < 9 * E::CC) {
+          const int u = q / E::CC, c = q - u * E::CC;
+          off = (hbase + (u / 3) * E::HW + (u % 3)) * E::COP + c * 8;
+        }
+        d = mma16<T>(wsrc.get(s, lane), lds_chunk<T>(DC, off), d);
+      }
+      const int Y = ty0 + oy, X = tx0 + ox;
+      if (Y < H && X < W) {
+        T* o = dfeat + (((size_t)n * H + Y) * W + X) * F;
+#pragma unroll
+        for (int g = 0; g < E::FC; ++g) stream_store(reinterpret_cast<HalfT*>(o + g * 8 + hh * 4), acc_group<T>(d, g));
+      }
+    }
+    constexpr int UNR = NT > 1 ? 1 : 3;            // x4: two accumulator tiles per wave, 128-register budget
+#pragma unroll UNR
+    for (int ot = 0; ot < E::NPT_O; ++ot) {
+      const int toy = (ot / (E::TW / 8)) * 4, tox = (ot % (E::TW / 8)) * 8;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        FragT b;
+        if (is_tap) b = tr_frag<T>(FT, s, lane, [=](int p) { return ((toy + (p >> 3) + ty) * E::HW + tox + (p & 7) + tx) * F; });
+        else b = tr_frag<T>(XI, s, lane, [=](int p) { return ((toy + (p >> 3) + ty) * I::IW + tox + (p & 7)) * 4; });
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+          const FragT a = tr_frag<T>(DC, s, lane, [=](int p) { return ((toy + (p >> 3) + 1) * E::HW + tox + (p & 7) + 1) * E::COP + 32 * ti; });
+          acc[ti] = mma16<T>(a, b, acc[ti]);
+        }
+      }
+    }
+  }
+  float* out = partial + (size_t)blockIdx.x * E::TAIL_TILES * 1024;
+  const int gbase = is_tap ? (ty * 3 + tx) * NT : (9 + ty) * NT;
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[((gbase + ti) * 16 + i) * 64 + lane] = acc[ti][i];
+}

@@ -212,3 +212,34 @@ def test_block_pair_bwd_data_bit_identical_to_two_launches(shape):
                                             None, None, n, h, w, f, 1, L.stream_ptr()), "pair bwd")
     torch.cuda.synchronize()
     assert torch.equal(p1, d1) and torch.equal(p0, d0)
+
+
+@pytest.mark.parametrize("f,r,shape", [(24, 4, (3, 48, 48)), (24, 2, (2, 20, 28)), (32, 3, (1, 7, 9)), (32, 4, (2, 13, 50))])
+def test_fused_tail_backward_bit_identical_to_two_launches(f, r, shape):
+    """sr_tail_bwd (data + weight gradients of the tail, one launch, bf16) == sr_tail_bwd_data + sr_tail_wgrad"""
+    from mobilesuperresolution_amd import _lib as L, hotpath as HP
+    n, h, w = shape
+    dev = torch.device("cuda", 0)
+    tb = HP.ends_tables(f, r, dev)
+    g = torch.Generator().manual_seed(31)
+    src_tail = (torch.randn(tb["tail_size"], generator=g) * 0.05).cuda()
+    src_tail[-2], src_tail[-1] = 0.0, 1.0
+    blob = HP.pack_tail(src_tail, f, r, torch.bfloat16)
+    feat = torch.randn(n, h, w, f, generator=g).cuda().bfloat16()
+    x = torch.rand(n, 3, h, w, generator=g).cuda()
+    dout = torch.randn(n, 3, r * h, r * w, generator=g).cuda()
+    wgs = 16
+    d_ref = torch.empty_like(feat)
+    p_ref = torch.zeros(wgs, tb["tail_slab"], device=dev)
+    HP.tail_bwd_data(dout, d_ref, blob, r)
+    L.check(L.lib().sr_tail_wgrad(dout.data_ptr(), feat.data_ptr(), x.data_ptr(), 0.5, p_ref.data_ptr(), wgs, n, h, w, f, r, 1,
+                                  L.stream_ptr()), "wgrad")
+    d_new = torch.full_like(feat, float("nan"))
+    p_new = torch.zeros(wgs, tb["tail_slab"], device=dev)
+    L.check(L.lib().sr_tail_bwd(dout.data_ptr(), feat.data_ptr(), x.data_ptr(), 0.5, blob.data_ptr(), d_new.data_ptr(),
+                                p_new.data_ptr(), wgs, n, h, w, f, r, 1, L.stream_ptr()), "fused")
+    torch.cuda.synchronize()
+    # slab columns outside the gather table come from LDS bytes past the 4-channel image rows (never used): compare
+    # what the network consumes, slab by slab
+    used = tb["tail_grad"]
+    assert torch.equal(d_new, d_ref) and torch.equal(p_new.index_select(1, used), p_ref.index_select(1, used))
