@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void unpack_all_kernel(float* __restrict__ dsr
   float acc = 0.f;
   if (rep < sg.reps && i < sg.n) {
     const float* p = sg.partial + (size_t)rep * sg.wgs * sg.slab + sg.sidx[i];
-#pragma unroll 4
+#pragma unroll 16                                    // many slabs (tail / head): keep 16 loads in flight per thread
     for (int w = q; w < sg.wgs; w += 4) acc += p[(size_t)w * sg.slab];
   }
   red[q][e] = acc;
