@@ -19,9 +19,8 @@ def rounding(weight: torch.Tensor, least_channel: int = 8) -> torch.Tensor:
     w = (weight >= 0.5).float()
     if least_channel > 0:
         v, _ = torch.topk(weight, least_channel, dim=0)
-        if torch.sum(w) >= least_channel:
-            return w
-        return (weight >= v[-1]).float()
+        # same selection as the reference's `if torch.sum(w) >= least_channel`, without the host sync it implies
+        return torch.where(torch.sum(w) >= least_channel, w, (weight >= v[-1]).float())
     return w
 
 

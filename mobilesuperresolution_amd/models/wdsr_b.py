@@ -37,6 +37,12 @@ __all__ = ["NAS_MODEL", "ModelOutput", "MyAggregationLayer", "Split_Block", "Con
 _DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
 
 
+@lru_cache(maxsize=None)
+def _const(device: torch.device, values: tuple) -> torch.Tensor:
+    """small fp32 constant on `device`, uploaded once (Tensor.new_tensor is a synchronous host-to-device copy)"""
+    return torch.tensor(values, dtype=torch.float32, device=device)
+
+
 def _hot_dtype(params) -> torch.dtype:
     name = getattr(params, "hot_dtype", None) or os.environ.get("SR_HOT_DTYPE", "fp32")
     return name if isinstance(name, torch.dtype) else _DTYPES[str(name).lower()]
@@ -56,8 +62,7 @@ class _WNConv(nn.Module):
         self.weight_v = nn.Parameter(v)
 
     def weight(self):
-        v = self.weight_v
-        return v * (self.weight_g / v.flatten(1).norm(dim=1).view(-1, 1, 1, 1))
+        return torch._weight_norm(self.weight_v, self.weight_g, 0)      # what nn.utils.weight_norm computes (one fused op)
 
 
 class Conv_sep(nn.Module):
@@ -77,13 +82,10 @@ class ConditionFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, alpha1, alpha2, beta1, beta2):
-        with torch.no_grad():
-            if alpha1 >= alpha2:
-                beta1.data = beta1.new_ones(1)
-                beta2.data = beta2.new_zeros(1)
-            else:
-                beta1.data = beta1.new_zeros(1)
-                beta2.data = beta2.new_ones(1)
+        with torch.no_grad():                       # same values as the reference's host-side if/else, no host sync
+            b1 = (alpha1 >= alpha2).to(beta1.dtype).reshape(1)
+            beta1.data = b1
+            beta2.data = 1.0 - b1
         return beta1, beta2
 
     @staticmethod
@@ -111,7 +113,7 @@ class _NasBlockFunction(torch.autograd.Function):
         dev, dt = yin.device, yin.dtype
         tb = _nas_dev_tables(f, dev.index if dev.index is not None else torch.cuda.current_device())
         src = torch.cat([t.detach().float().reshape(-1) for t in (wdw3, wdw5, wdw7, bdw, wpw, bpw, mg, ms, mg * ms)]
-                        + [yin.new_tensor([0.0, 1.0], dtype=torch.float32)])
+                        + [_const(yin.device, (0.0, 1.0))])
         assert src.numel() == tb["off"]["size"]
         dwp = src.index_select(0, tb["dwp"]).contiguous()
         frags = src.index_select(0, tb["frags"]).to(dt).contiguous()
@@ -200,7 +202,7 @@ class Split_Block(nn.Module):
             raise L.HotpathError("Split_Block (MI355X hot path) needs CUDA/HIP tensors; there is no CPU fallback")
         dt = getattr(self, "hot_dtype", torch.float32)
         yin = x.permute(0, 2, 3, 1).to(dt).contiguous()
-        y = self._run(yin, x.new_ones(self.num_residual_units), x.new_tensor([0.0, 1.0]))
+        y = self._run(yin, x.new_ones(self.num_residual_units), _const(x.device, (0.0, 1.0)))
         return y.permute(0, 3, 1, 2).float()
 
     def forward(self, x):
@@ -219,6 +221,13 @@ class MyAggregationLayer(Split_Block):
         self.beta2 = nn.Parameter(torch.ones(1))
         init.uniform_(self.alpha2, 0.8, 1)
 
+    def _skipped(self) -> bool:
+        """eval-time gate alpha1 >= alpha2 as a host bool, read back once per parameter version"""
+        key = (self.alpha1.data_ptr(), self.alpha1._version, self.alpha2.data_ptr(), self.alpha2._version)
+        if getattr(self, "_skip_key", None) != key:
+            self._skip_val, self._skip_key = bool(self.alpha1 >= self.alpha2), key
+        return self._skip_val
+
     def forward(self, y, mg, speed_curr, speed_accu):
         """y: NHWC hot tensor BEFORE the global mask; mg: (F,) effective global mask (applied in-kernel).
         Returns (y_out NHWC, speed_accu) with the reference's train / eval semantics (:517-546)."""
@@ -227,10 +236,10 @@ class MyAggregationLayer(Split_Block):
             self.beta1.data, self.beta2.data = beta1.detach(), beta2.detach()
             out = self._run(y, mg, torch.cat([beta1, beta2]))
             return out, beta2 * speed_curr + speed_accu
-        if self.alpha1 >= self.alpha2:
+        if self._skipped():
             out = (y.float() * mg.view(1, 1, 1, -1)).to(y.dtype)          # skipped block: only the global mask
         else:
-            out = self._run(y, mg, y.new_tensor([0.0, 1.0], dtype=torch.float32))
+            out = self._run(y, mg, _const(y.device, (0.0, 1.0)))
         return out, speed_accu + self.beta2 * speed_curr
 
 
@@ -257,9 +266,11 @@ class BlockBSpeedEstimator(nn.Module):
     def estimateByMyMask(self, module, block_mask):
         """sum_k (c_split + 0.2 c_mask) k^2 alpha_k / 40, alpha RAW (speed_estimator.py:57-76); both channel counts
         use rounding() with its default least_channel=8 (get_unmask_number, :79-83)."""
-        c_mask = rounding(block_mask.weight.detach()).sum()
+        c_mask = getattr(block_mask, "_c_mask_cached", None)          # NAS_MODEL.forward computes it once per call
+        if c_mask is None:
+            c_mask = rounding(block_mask.weight.detach()).sum()
         c_split = rounding(module.split.weight.detach()).sum()
-        k2 = module.alpha.new_tensor([9.0, 25.0, 49.0])
+        k2 = _const(module.alpha.device, (9.0, 25.0, 49.0))
         return ((c_split + 0.2 * c_mask) * k2 * module.alpha.detach() / 40).sum().reshape(1)
 
     @torch.no_grad()
@@ -356,9 +367,13 @@ class NAS_MODEL(nn.Module):
         y = _HeadFunction.apply(x, self.head.weight(), self.head.bias, f, dt, self.image_mean)
         speed_accu = x.new_zeros(1)
         mg = self.mask.effective()
-        for module in self.body:
-            speed_curr = self.speed_estimator.estimateByMyMask(module, self.mask)
-            y, speed_accu = module(y, mg, speed_curr, speed_accu)
+        self.mask._c_mask_cached = rounding(self.mask.weight.detach()).sum()   # shared by every block's latency term
+        try:
+            for module in self.body:
+                speed_curr = self.speed_estimator.estimateByMyMask(module, self.mask)
+                y, speed_accu = module(y, mg, speed_curr, speed_accu)
+        finally:
+            self.mask._c_mask_cached = None
         y = (y.float() * mg.view(1, 1, 1, -1)).to(dt)                         # y = self.mask(y) before the tail (:118-119)
         btot = self.tail.bias + self.skip.bias + self.image_mean
         out = _TailFunction.apply(y, x, self.tail.weight(), self.skip.weight(), btot, self.scale, self.image_mean)
