@@ -109,6 +109,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if os.environ.get("SR_BENCH_SHARED_GPU") == "1":    # rehearsal of the N > 1 control flow on a one-GPU box (with gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_ddp = world > 1 or args.force_ddp
@@ -117,7 +119,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", init_method="env://")        # nccl == RCCL on ROCm
+        dist.init_process_group(backend=os.environ.get("SR_BENCH_BACKEND", "nccl"), init_method="env://")   # nccl == RCCL
 
     from mobilesuperresolution_amd import hotpath as HP
     from mobilesuperresolution_amd.models import get_model
@@ -162,7 +164,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     # forward-only (inference) throughput, same batch
     model.eval()
@@ -176,6 +178,17 @@ def main():
         torch.cuda.synchronize()
         fwd_elapsed = time.perf_counter() - tf
     model.train()
+
+    # whole forward / backward calls, for the record: EVERY rank runs these steps (under DDP they contain the
+    # gradient all-reduce, a collective), only rank 0 keeps the timings
+    from mobilesuperresolution_amd import _lib as L
+    timer = L.KernelTimer()
+    if rank == 0:
+        L.set_timer(timer)
+    for _ in range(5):
+        step()
+    L.set_timer(None)
+    sync()
 
     if rank == 0:
         # ---- roofline leg: the graded kernel (fused residual block forward), launched back to back from
@@ -215,12 +228,6 @@ def main():
         units = 2 if pair else 1                              # residual blocks per launch
         alg_launch = units * alg["sr_wdsr_block_fwd"]
         achieved = alg_launch / (us * 1e-6) / 1e9
-        # whole forward / backward calls, for the record
-        timer = L.KernelTimer()
-        L.set_timer(timer)
-        for _ in range(5):
-            step()
-        L.set_timer(None)
         calls = {k: round(v[1] * 1e3, 1) for k, v in timer.summary().items()}
         traffic = None                                   # PMC bytes per launch, collected offline with rocprofv3 --pmc
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_block2_fwd.json" if pair else "r01_pmc_block_fwd.json")
@@ -244,7 +251,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"WDSR-B x{SCALE}, {BLOCKS} blocks / {UNITS} units, {LR}x{LR} LR patches, "
-                                   f"batch {BATCH} per GPU, fwd+L1+bwd+Adam" + (", DDP/RCCL" if use_ddp else ""),
+                                   f"batch {BATCH} per GPU, fwd+L1+bwd+Adam" + (f", DDP/{'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()}" if use_ddp else ""),
                        "global_batch": BATCH * world, "parallelism": f"dp{world}"},
             "forward_only_HR_Mpix_s": round(BATCH * HR_MPIX_PER_PATCH * args.steps / fwd_elapsed, 2),
             "final_loss": round(final_loss, 5),
