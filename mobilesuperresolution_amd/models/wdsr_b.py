@@ -165,6 +165,93 @@ class _NasBlockFunction(torch.autograd.Function):
         return gyin, g_wdw[0], g_wdw[1], g_wdw[2], g_bdw, g_wpw, g_bpw, g_mg, g_ms, g_p, g_beta
 
 
+class _NasBodyFunction(torch.autograd.Function):
+    """Every block of the supernet body in one autograd node: per block the same two forward / two backward kernels
+    as _NasBlockFunction, but the parameter tables of all blocks are packed by a handful of batched ops (one cat,
+    three gathers) and all gradients are gathered at once, instead of ~170 small launches per block.
+    Inputs are stacked over blocks: WDWk (nb, F, 1, k, k), BDW / BPW (nb, 3, F), WPW (nb, 3, F, F, 1, 1), mg (F,),
+    MS (nb, F), P (nb, 3), BETA (nb, 2)."""
+
+    @staticmethod
+    def forward(ctx, y0, WDW3, WDW5, WDW7, BDW, WPW, BPW, mg, MS, P, BETA):
+        n, h, w, f = y0.shape
+        nb = WDW3.shape[0]
+        dev, dt = y0.device, y0.dtype
+        tb = _nas_dev_tables(f, dev.index if dev.index is not None else torch.cuda.current_device())
+        mgf, MSf = mg.detach().float(), MS.detach().float()
+        src = torch.cat([WDW3.detach().float().reshape(nb, -1), WDW5.detach().float().reshape(nb, -1),
+                         WDW7.detach().float().reshape(nb, -1), BDW.detach().float().reshape(nb, -1),
+                         WPW.detach().float().reshape(nb, -1), BPW.detach().float().reshape(nb, -1),
+                         mgf.reshape(1, f).expand(nb, f), MSf, mgf.reshape(1, f) * MSf,
+                         _const(dev, (0.0, 1.0)).reshape(1, 2).expand(nb, 2)], dim=1)
+        assert src.shape[1] == tb["off"]["size"]
+        dwp = src.index_select(1, tb["dwp"])
+        frags = src.index_select(1, tb["frags"]).to(dt)
+        tabs = src.index_select(1, tb["tabs"])
+        scal = torch.cat([P.detach().float(), BETA.detach().float()[:, 1:2]], dim=1).contiguous()
+        code = L.DTYPE_CODE[dt]
+        ys = torch.empty((nb + 1, n, h, w, f), dtype=dt, device=dev)
+        ys[0] = y0
+        V = torch.empty((nb, 3, n, h, w, f), dtype=dt, device=dev)
+        st, lib = L.stream_ptr, L.lib()
+        for i in range(nb):
+            L.launch("sr_nas_dw_fwd", lib.sr_nas_dw_fwd, ys[i].data_ptr(), V[i].data_ptr(), dwp[i].data_ptr(), n, h, w, f, code, st())
+            L.launch("sr_nas_pw_fwd", lib.sr_nas_pw_fwd, ys[i].data_ptr(), V[i].data_ptr(), ys[i + 1].data_ptr(),
+                     frags[i].data_ptr(), tabs[i].data_ptr(), scal[i].data_ptr(), n, h, w, f, code, st())
+        ctx.save_for_backward(ys, V, dwp, frags, tabs, scal, MSf, P.detach().float(), BETA.detach().float())
+        return ys[nb]
+
+    @staticmethod
+    def backward(ctx, gy):
+        ys, V, dwp, frags, tabs, scal, MS, P, BETA = ctx.saved_tensors
+        nb, n, h, w, f = V.shape[0], V.shape[2], V.shape[3], V.shape[4], V.shape[5]
+        dev, dt = ys.device, ys.dtype
+        tb = _nas_dev_tables(f, dev.index if dev.index is not None else torch.cuda.current_device())
+        code = L.DTYPE_CODE[dt]
+        wgs = 64
+        GZ = torch.empty_like(V[0])
+        part_pw = torch.empty((nb, wgs, tb["pw_slab"]), dtype=torch.float32, device=dev)
+        part_dw = torch.empty((nb, wgs, tb["dw_slab"]), dtype=torch.float32, device=dev)
+        g = gy.contiguous()
+        gbuf = [torch.empty_like(g), torch.empty_like(g)]
+        st, lib = L.stream_ptr, L.lib()
+        for i in range(nb - 1, -1, -1):
+            gin = gbuf[i & 1]
+            L.launch("sr_nas_pw_bwd", lib.sr_nas_pw_bwd, ys[i].data_ptr(), V[i].data_ptr(), g.data_ptr(), GZ.data_ptr(),
+                     frags[i].data_ptr(), tabs[i].data_ptr(), scal[i].data_ptr(), part_pw[i].data_ptr(), wgs, n, h, w, f, code, st())
+            L.launch("sr_nas_dw_bwd", lib.sr_nas_dw_bwd, ys[i].data_ptr(), GZ.data_ptr(), g.data_ptr(), gin.data_ptr(),
+                     dwp[i].data_ptr(), part_dw[i].data_ptr(), wgs, n, h, w, f, code, st())
+            g = gin
+        spw, sdw = part_pw.sum(1), part_dw.sum(1)                                      # (nb, slab)
+        g_wpw = spw.index_select(1, tb["g_wpw"]).view(nb, 3, f, f, 1, 1)
+        g_bpw = spw.index_select(1, tb["g_bpw"]).view(nb, 3, f)
+        r = spw.index_select(1, tb["g_r"]).view(nb, 3, f)                             # r_k[c] = sum gy[c] relu(u_k)[c]
+        sxy = spw[:, tb["sxy"]]
+        g_wdw = [sdw.index_select(1, tb["g_wdw"][i]).view(nb, f, 1, k, k) for i, k in enumerate((3, 5, 7))]
+        g_bdw = sdw.index_select(1, tb["g_bdw"]).view(nb, 3, f)
+        sA, sB = sdw.index_select(1, tb["g_sA"]), sdw.index_select(1, tb["g_sB"])      # (nb, F)
+        b2 = BETA[:, 1]                                                                # (nb,)
+        q = (r * MS.view(nb, 1, f)).sum(2)                                             # q_k = sum_c ms[c] r_k[c]
+        g_p = b2.view(nb, 1) * q
+        g_beta = torch.stack([sxy, sxy + (P * q).sum(1)], dim=1)
+        g_ms = sA + b2.view(nb, 1) * (P.view(nb, 3, 1) * r).sum(1)
+        g_mg = sB.sum(0)
+        return g, g_wdw[0], g_wdw[1], g_wdw[2], g_bdw, g_wpw, g_bpw, g_mg, g_ms, g_p, g_beta
+
+
+class _GateFunction(torch.autograd.Function):
+    """ConditionFunction over all blocks at once: (1,0) where alpha1 >= alpha2 else (0,1); straight-through."""
+
+    @staticmethod
+    def forward(ctx, A1, A2):
+        b1 = (A1 >= A2).to(A1.dtype)
+        return torch.stack([b1, 1.0 - b1], dim=1)                                      # (nb, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, 0], g[:, 1]
+
+
 class Split_Block(nn.Module):
     """reference wdsr_b.py:405-501 (block_type 'normal', seperate_type True)"""
 
@@ -365,19 +452,63 @@ class NAS_MODEL(nn.Module):
         x = x.contiguous().float()
         f, dt = self.num_residual_units, self.hot_dtype
         y = _HeadFunction.apply(x, self.head.weight(), self.head.bias, f, dt, self.image_mean)
-        speed_accu = x.new_zeros(1)
         mg = self.mask.effective()
-        self.mask._c_mask_cached = rounding(self.mask.weight.detach()).sum()   # shared by every block's latency term
-        try:
-            for module in self.body:
-                speed_curr = self.speed_estimator.estimateByMyMask(module, self.mask)
-                y, speed_accu = module(y, mg, speed_curr, speed_accu)
-        finally:
-            self.mask._c_mask_cached = None
+        y, speed_accu = self._body(y, mg)
         y = (y.float() * mg.view(1, 1, 1, -1)).to(dt)                         # y = self.mask(y) before the tail (:118-119)
         btot = self.tail.bias + self.skip.bias + self.image_mean
         out = _TailFunction.apply(y, x, self.tail.weight(), self.skip.weight(), btot, self.scale, self.image_mean)
         return out, speed_accu
+
+    def _body(self, y, mg):
+        """All MyAggregationLayer blocks (reference wdsr_b.py:111-117 with :517-546 per block) through ONE autograd node:
+        parameters are stacked over blocks so that weight-norm, masks, gates, softmax and the latency terms are a few
+        batched ops, not a few dozen per block.  Returns (y NHWC, speed_accu (1,))."""
+        blocks = list(self.body)
+        if not self.training:                       # eval: a skipped block only applies the (idempotent 0/1) global mask
+            blocks = [m for m in blocks if not m._skipped()]
+        speed_all = list(self.body)
+        dev = y.device
+        # latency head, reference speed_estimator.py:57-76 (raw alpha, rounding() with its default least_channel = 8)
+        with torch.no_grad():
+            c_mask = rounding(self.mask.weight.detach()).sum()
+            W = torch.stack([m.split.weight.detach().reshape(-1) for m in speed_all])              # (NB, F)
+            kth = torch.topk(W, 8, dim=1).values[:, -1:]
+            hard = (W >= 0.5).float()
+            c_split = torch.where(hard.sum(1, keepdim=True) >= 8, hard, (W >= kth).float()).sum(1)
+            A = torch.stack([m.alpha.detach() for m in speed_all])                                  # (NB, 3)
+            speed_curr = ((c_split + 0.2 * c_mask).view(-1, 1) * _const(dev, (9.0, 25.0, 49.0)).view(1, 3) * A / 40).sum(1)
+        if self.training:
+            gates = _GateFunction.apply(torch.cat([m.alpha1 for m in speed_all]), torch.cat([m.alpha2 for m in speed_all]))
+            for i, m in enumerate(speed_all):                                                       # reference :521-523
+                m.beta1.data, m.beta2.data = gates.detach()[i, 0:1], gates.detach()[i, 1:2]
+            speed_accu = (gates[:, 1] * speed_curr).sum().reshape(1)
+        else:
+            gates = None
+            speed_accu = (torch.cat([m.beta2 for m in speed_all]) * speed_curr).sum().reshape(1)
+        if not blocks:
+            return y, speed_accu
+        idx = [i for i, m in enumerate(speed_all) if m in blocks] if len(blocks) != len(speed_all) else None
+
+        def wn(k, j):                                # weight-normalised conv j (0 depthwise, 2 pointwise) of branch k
+            convs = [m.body[k][0].body[j] for m in blocks]
+            v = torch.cat([c.weight_v for c in convs])
+            gsc = torch.cat([c.weight_g for c in convs])
+            return torch._weight_norm(v, gsc, 0).view(len(blocks), *convs[0].weight_v.shape)
+        nbk = len(blocks)
+        WDW = [wn(k, 0) for k in ("3", "5", "7")]
+        WPW = torch.stack([wn(k, 2) for k in ("3", "5", "7")], dim=1)                                # (nb, 3, F, F, 1, 1)
+        BDW = torch.stack([m.body[k][0].body[0].bias for m in blocks for k in ("3", "5", "7")]).view(nbk, 3, -1)
+        BPW = torch.stack([m.body[k][0].body[2].bias for m in blocks for k in ("3", "5", "7")]).view(nbk, 3, -1)
+        SW = torch.stack([m.split.weight.reshape(-1) for m in blocks])                              # (nb, F)
+        SWd = SW.detach()
+        MS = SW - (SWd - (SWd >= 0.5).float())                   # BinaryConv2d(least_channel=0): value 0/1, gradient 1
+        P = F.softmax(torch.stack([m.alpha for m in blocks]), dim=1)
+        if self.training:
+            BETA = gates if idx is None else gates[idx]
+        else:
+            BETA = _const(dev, (0.0, 1.0)).view(1, 2).expand(nbk, 2)
+        y = _NasBodyFunction.apply(y, WDW[0], WDW[1], WDW[2], BDW, WPW, BPW, mg, MS, P, BETA)
+        return y, speed_accu
 
     # ---- search-control surface used by search.py:83-87,292,331-337,374-380 ----
     @torch.no_grad()
