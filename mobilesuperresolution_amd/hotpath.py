@@ -17,6 +17,13 @@ from . import packing as P
 KernelTimer, set_timer, _launch = L.KernelTimer, L.set_timer, L.launch
 
 
+
+@lru_cache(maxsize=None)
+def const01(device: torch.device, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """the [0, 1] constant slots of a canonical source vector, uploaded once per device
+    (Tensor.new_tensor is a synchronous host-to-device copy: it drains the GPU queue on every call)"""
+    return torch.tensor([0.0, 1.0], dtype=dtype, device=device)
+
 def block_dims(F: int) -> Tuple[int, int, int]:
     """(F, E, L) of the reference Block: expand 6, linear 0.84 (models/basic_wdsr_b.py:105-106)."""
     return F, int(F * 6), int(F * 0.84)
@@ -54,7 +61,7 @@ def block_src(w1: torch.Tensor, w2: torch.Tensor, w3: torch.Tensor, b1: torch.Te
     """Canonical per-block source vectors [NB, S] from stacked effective weights/biases
     (w1 [NB,E,F], w2 [NB,L,E], w3 [NB,F,L,3,3], b* [NB,...]); differentiable."""
     nb = w1.shape[0]
-    const = w1.new_tensor([0.0, 1.0]).expand(nb, 2)
+    const = const01(w1.device, w1.dtype).expand(nb, 2)
     return torch.cat([w1.reshape(nb, -1), w2.reshape(nb, -1), w3.reshape(nb, -1), b1, b2, b3, const], dim=1)
 
 
@@ -120,12 +127,12 @@ def ends_tables(F: int, R: int, device: torch.device):
 
 def head_src(wh: torch.Tensor, bh: torch.Tensor) -> torch.Tensor:
     """canonical head source: wh (F,3,3,3) | bh (F) | 0 | 1"""
-    return torch.cat([wh.reshape(-1), bh, wh.new_tensor([0.0, 1.0])])
+    return torch.cat([wh.reshape(-1), bh, const01(wh.device, wh.dtype)])
 
 
 def tail_src(wt: torch.Tensor, ws: torch.Tensor, btot: torch.Tensor) -> torch.Tensor:
     """canonical tail source: wt (CO,F,3,3) | ws (CO,3,5,5) | bt + bs + mean (CO) | 0 | 1"""
-    return torch.cat([wt.reshape(-1), ws.reshape(-1), btot, wt.new_tensor([0.0, 1.0])])
+    return torch.cat([wt.reshape(-1), ws.reshape(-1), btot, const01(wt.device, wt.dtype)])
 
 
 def pack_ends(src_head: torch.Tensor, src_tail: torch.Tensor, F: int, R: int, dtype: torch.dtype):

@@ -42,7 +42,7 @@ def _pack(conv: nn.Conv2d, dtype):
     """one conv's packed weights (per-op entry points / tests)"""
     w = conv.weight
     idx, _, size = _tables(w.shape[1], w.device.index if w.device.index is not None else torch.cuda.current_device())
-    src = torch.cat([w.detach().reshape(-1).float(), conv.bias.detach().float(), w.new_tensor([0.0, 1.0])])
+    src = torch.cat([w.detach().reshape(-1).float(), conv.bias.detach().float(), torch.tensor([0.0, 1.0], device=w.device)])
     assert src.numel() == size
     return src.index_select(0, idx).to(dtype).contiguous()
 
