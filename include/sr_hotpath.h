@@ -179,6 +179,10 @@ int sr_nas_pw_bwd(const void* yin, const void* V, const void* gy, void* GZ, cons
 /* partial[wgs][88*32]: dWdw[83 taps][32] | dbd[3][32] | sum(g_br*mg*yin)[32] | sum(g_x*yin)[32]. */
 int sr_nas_dw_bwd(const void* yin, const void* GZ, const void* gy, void* gyin, const float* dwp, float* partial,
                   int wgs, int N, int H, int W, int F, int dtype, sr_stream_t stream);
+/* Depthwise weight gradients dWdw[83 taps][32] of the same slab (same `wgs`), on the matrix cores; call after
+ * sr_nas_dw_bwd on the same stream (it fills the part of each slab that sr_nas_dw_bwd leaves untouched). */
+int sr_nas_dw_wgrad(const void* yin, const void* GZ, const float* dwp, float* partial, int wgs, int N, int H, int W,
+                    int F, int dtype, sr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Whole-network entry points: everything BASIC_MODEL.forward (models/basic_wdsr_b.py:85-93) and its

@@ -28,6 +28,7 @@ SIGNATURES = {
     "sr_c3_trunk_fwd": ([_P] * 5 + [_I] * 6 + [_P], _I),
     "sr_c3_trunk_bwd": ([_P] * 9 + [_I] * 7 + [_P], _I),
     "sr_tail_bwd": ([_P, _P, _P, _F, _P, _P, _P] + [_I] * 7 + [_P], _I),
+    "sr_nas_dw_wgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block_fwd_stamps": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P], _I),
     "sr_wdsr_block_fwd_repeat": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block_bwd_data": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),

@@ -317,8 +317,8 @@ __global__ __launch_bounds__(384) void nas_pw_bwd_kernel(const T* __restrict__ y
 
 // ---------------------------------------------------------------------------------------------
 // depthwise backward: g_br = sum_k dw_k^T(GZ_k); g_x = gy + ms g_br; g_yin = mg g_x;
-// slab: dWdw[83 taps][32] | dbd[3][32] | sA[c] = sum g_br mg yin | sB[c] = sum g_x yin.
-// (a) weight gradients: lanes = channels, the taps of each stencil are dealt over the 8 waves;
+// slab: dWdw[83 taps][32] (filled by nas_dw_wgrad_kernel) | dbd[3][32] | sA[c] = sum g_br mg yin | sB[c] = sum g_x yin.
+// (a) bias gradients: lanes = channels;
 // (b) data gradient: (pixel group, chunk) items as in the forward.  grid = (wgs), persistent over tiles.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int F>
@@ -329,17 +329,13 @@ __global__ __launch_bounds__(512) void nas_dw_bwd_kernel(const T* __restrict__ y
   typedef NasCfg<F> C;
   typedef typename FragOf<T>::type FragT;
   constexpr int MAXIT = (C::NITEM + 7) / 8;
-  constexpr int STAGE_BYTES = 2 * C::P3_ELEMS * (int)sizeof(T);
+  constexpr int STAGE_BYTES = C::P3_ELEMS * (int)sizeof(T);
   constexpr int LDS_BYTES = STAGE_BYTES > C::DWB_SLAB * 4 ? STAGE_BYTES : C::DWB_SLAB * 4;
   __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES];
-  T* const X1 = reinterpret_cast<T*>(smem_raw);
-  T* const GT = X1 + C::P3_ELEMS;
+  T* const GT = reinterpret_cast<T*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ch = lane & 31, half = lane >> 5;
-  // weight-gradient accumulators of this wave's taps: 2 slots for the 3x3, 4 for the 5x5, 7 for the 7x7
-  float accw[13], accb[3], sA[MAXIT][8], sB[MAXIT][8];
-#pragma unroll
-  for (int i = 0; i < 13; ++i) accw[i] = 0.f;
+  float accb[3], sA[MAXIT][8], sB[MAXIT][8];
 #pragma unroll
   for (int i = 0; i < 3; ++i) accb[i] = 0.f;
 #pragma unroll
@@ -356,12 +352,9 @@ __global__ __launch_bounds__(512) void nas_dw_bwd_kernel(const T* __restrict__ y
     for (int i = 0; i < MAXIT; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) gbr[i][j] = 0.f;
-    __syncthreads();
-    nas_stage_halo3<T, C, 512>(X1, yin + img, dwp + C::M1, H, W, ty0, tx0, tid);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int ks = 3 + 2 * k, off = 3 - ks / 2, wbase = nas_woff(k);
-      const int sbase = k == 0 ? 0 : (k == 1 ? 2 : 6), nslot = k == 0 ? 2 : (k == 1 ? 4 : 7);
       __syncthreads();
       nas_stage_halo3<T, C, 512>(GT, GZ + k * vstride + img, nullptr, H, W, ty0, tx0, tid);
       __syncthreads();
@@ -385,21 +378,12 @@ __global__ __launch_bounds__(512) void nas_dw_bwd_kernel(const T* __restrict__ y
           }
         }
       }
-      // (a) weight gradient: lane = channel, taps tp = wave, wave + 8, ...; two lane halves split the pixels
-      if (ch < F) {
-        const int ntap = ks * ks;
+      // (a) bias gradient of the depthwise conv: lane = channel, the two lane halves split the pixels, the three
+      //     stencils go to waves 0..2 (the weight gradients are nas_dw_wgrad_kernel's)
+      if (ch < F && wave == k) {
         for (int p = half; p < C::NPXC; p += 2) {
           const int oy = p / C::TW, ox = p - oy * C::TW;
-          const float gz = (float)GT[((oy + 3) * C::PW + ox + 3) * F + ch];
-          if (wave == 0) accb[k] += gz;
-#pragma unroll
-          for (int i = 0; i < 7; ++i) {
-            const int tp = wave + 8 * i;
-            if (i < nslot && tp < ntap) {
-              const int ty = tp / ks, tx = tp - ty * ks;
-              accw[sbase + i] += gz * (float)X1[((oy + off + ty) * C::PW + ox + off + tx) * F + ch];
-            }
-          }
+          accb[k] += (float)GT[((oy + 3) * C::PW + ox + 3) * F + ch];
         }
       }
     }
@@ -435,16 +419,11 @@ __global__ __launch_bounds__(512) void nas_dw_bwd_kernel(const T* __restrict__ y
   __syncthreads();
   if (ch < F) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int ks = 3 + 2 * k, ntap = ks * ks, tbase = nas_woff(k) / 32;
-      const int sbase = k == 0 ? 0 : (k == 1 ? 2 : 6), nslot = k == 0 ? 2 : (k == 1 ? 4 : 7);
-#pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        const int tp = wave + 8 * i;
-        if (i < nslot && tp < ntap) atomicAdd(slab + (tbase + tp) * 32 + ch, accw[sbase + i]);
+    for (int k = 0; k < 3; ++k)
+      if (wave == k) {
+        const float v = accb[k] + __shfl_xor(accb[k], 32);
+        if (half == 0) slab[(83 + k) * 32 + ch] = v;
       }
-      if (wave == 0) atomicAdd(slab + (83 + k) * 32 + ch, accb[k]);
-    }
   }
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
@@ -461,4 +440,96 @@ __global__ __launch_bounds__(512) void nas_dw_bwd_kernel(const T* __restrict__ y
   __syncthreads();
   float* out = partial + (size_t)blockIdx.x * C::DWB_SLAB;
   for (int i = tid; i < C::DWB_SLAB; i += 512) out[i] = slab[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// depthwise weight gradients on the matrix cores: dW_k[tap][c] = sum_px GZ_k[px][c] * x1[px + tap][c] is the
+// DIAGONAL of the 32x32 product GZ_k^T x1(shifted); computing the whole product with MFMA (pixels contracted
+// through transposed LDS reads, as the 3x3 weight gradients do) and keeping the diagonal is ~30x faster than the
+// per-tap VALU reduction it replaces (one 2-byte LDS read per multiply-add).  12 waves; wave w owns taps
+// w, w + 12, ... of each stencil (1 + 3 + 5 accumulator tiles).  Writes the dWdw[83][32] part of the slab.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int F, int K>
+SR_DEV void nas_dw_wgrad_k(T* X1, T* GT, const T* __restrict__ yin, const T* __restrict__ GZk, const float* __restrict__ dwp,
+                           float* __restrict__ out, int N, int H, int W, int tiles_x, int tiles_per_img) {
+  typedef NasCfg<F> C;
+  typedef typename FragOf<T>::type FragT;
+  constexpr int NTHREADS = 768, KS = 3 + 2 * K, OFF = 3 - KS / 2, NTAP = KS * KS, NSLOT = 1 + 2 * K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  f32x16 acc[NSLOT];
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i) acc[i] = zero16();
+  for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
+    const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
+    const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+    const size_t img = (size_t)n * H * W * F;
+    __syncthreads();
+    for (int idx = tid; idx < (C::NP3 + 2) * 4; idx += NTHREADS) {
+      const int hp = idx >> 2, c = idx & 3;
+      FragT v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (T)0.f;
+      if (hp < C::NP3 && c < C::FC) {
+        const int hy = hp / C::PW, hx = hp - hy * C::PW;
+        const int Y = ty0 - 3 + hy, X = tx0 - 3 + hx;
+        if (Y >= 0 && Y < H && X >= 0 && X < W) {
+          v = *reinterpret_cast<const FragT*>(yin + img + ((size_t)Y * W + X) * F + c * 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (T)((float)v[j] * dwp[C::M1 + c * 8 + j]);
+        }
+      }
+      *reinterpret_cast<FragT*>(X1 + idx * 8) = v;
+    }
+    nas_stage_vt<T, C, NTHREADS>(GT, GZk + img, H, W, ty0, tx0, tid);
+    __syncthreads();
+#pragma unroll 1
+    for (int ot = 0; ot < C::NPT_O; ++ot) {
+      const int toy = (ot / (C::TW / 8)) * 4, tox = (ot % (C::TW / 8)) * 8;
+      auto rowg = [=](int p) { return ((toy + (p >> 3)) * C::TW + tox + (p & 7)) * 32; };
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const FragT a = tr_frag<T>(GT, s, lane, rowg);
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+          const int tp = wave + 12 * i;
+          if (tp < NTAP) {
+            const int ty = tp / KS, tx = tp - ty * KS;
+            auto rowx = [=](int p) { return ((toy + (p >> 3) + OFF + ty) * C::PW + tox + (p & 7) + OFF + tx) * 32; };
+            acc[i] = mma16<T>(a, tr_frag<T>(X1, s, lane, rowx), acc[i]);
+          }
+        }
+      }
+    }
+  }
+  // diagonal of every tile: accumulator register q of lane (r, hh) is row (q & 3) + 8 (q >> 2) + 4 hh, column r
+  const bool mine = hh == ((r >> 2) & 1);
+  const int isel = (r & 3) + 4 * (r >> 3);
+  const int tbase = (K == 0 ? 0 : (K == 1 ? 9 : 34));
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i) {
+    const int tp = wave + 12 * i;
+    if (tp < NTAP) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v = (q == isel) ? acc[i][q] : v;
+      if (mine) out[(tbase + tp) * 32 + r] = v;
+    }
+  }
+}
+
+// grid = (wgs, 3): blockIdx.y = stencil (3x3, 5x5, 7x7); each workgroup walks the tiles t = blockIdx.x, += gridDim.x
+template <typename T, int F>
+__global__ __launch_bounds__(768) void nas_dw_wgrad_kernel(const T* __restrict__ yin, const T* __restrict__ GZ,
+                                                           const float* __restrict__ dwp, float* __restrict__ partial,
+                                                           int N, int H, int W, int tiles_x, int tiles_per_img,
+                                                           long vstride) {
+  typedef NasCfg<F> C;
+  constexpr int X_ELEMS = (C::NP3 + 2) * 32;
+  __shared__ __attribute__((aligned(16))) T smem[X_ELEMS + C::VT_ELEMS];
+  T* const X1 = smem;                      // m1 * yin with a 3-pixel halo, [NP3 + 2][32] (channels >= F zero)
+  T* const GT = smem + X_ELEMS;            // core tile of GZ_k, [NPXC + 1][32]
+  float* out = partial + (size_t)blockIdx.x * C::DWB_SLAB;
+  if (blockIdx.y == 0) nas_dw_wgrad_k<T, F, 0>(X1, GT, yin, GZ, dwp, out, N, H, W, tiles_x, tiles_per_img);
+  else if (blockIdx.y == 1) nas_dw_wgrad_k<T, F, 1>(X1, GT, yin, GZ + vstride, dwp, out, N, H, W, tiles_x, tiles_per_img);
+  else nas_dw_wgrad_k<T, F, 2>(X1, GT, yin, GZ + 2 * vstride, dwp, out, N, H, W, tiles_x, tiles_per_img);
 }

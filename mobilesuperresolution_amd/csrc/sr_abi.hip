@@ -519,6 +519,19 @@ extern "C" int sr_nas_dw_bwd(const void* yin, const void* GZ, const void* gy, vo
   return 0;
 }
 
+extern "C" int sr_nas_dw_wgrad(const void* yin, const void* GZ, const float* dwp, float* partial, int wgs, int N, int H,
+                               int W, int F, int dtype, sr_stream_t stream) {
+  if (!yin || !GZ || !dwp || !partial || wgs <= 0 || N <= 0 || H <= 0 || W <= 0) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const long vs = (long)N * H * W * F;
+#define CALL(T, F_) { typedef NasCfg<F_> C; const int tx = (W + C::TW - 1) / C::TW, tpi = tx * ((H + C::TH - 1) / C::TH); \
+    hipLaunchKernelGGL((nas_dw_wgrad_kernel<T, F_>), dim3(wgs, 3), dim3(768), 0, st, (const T*)yin, (const T*)GZ, dwp, partial, N, H, W, tx, tpi, vs); }
+  SR_NAS_DISPATCH(CALL)
+#undef CALL
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // whole network
 // ------------------------------------------------------------------------------------------

@@ -148,6 +148,8 @@ class _NasBlockFunction(torch.autograd.Function):
                  frags.data_ptr(), tabs.data_ptr(), scal.data_ptr(), part_pw.data_ptr(), wgs, n, h, w, f, code, st())
         L.launch("sr_nas_dw_bwd", L.lib().sr_nas_dw_bwd, yin.data_ptr(), GZ.data_ptr(), gy.data_ptr(), gyin.data_ptr(),
                  dwp.data_ptr(), part_dw.data_ptr(), wgs, n, h, w, f, code, st())
+        L.launch("sr_nas_dw_wgrad", L.lib().sr_nas_dw_wgrad, yin.data_ptr(), GZ.data_ptr(), dwp.data_ptr(), part_dw.data_ptr(),
+                 wgs, n, h, w, f, code, st())
         spw, sdw = part_pw.sum(0), part_dw.sum(0)
         g_wpw = spw.index_select(0, tb["g_wpw"]).view(3, f, f, 1, 1)
         g_bpw = spw.index_select(0, tb["g_bpw"]).view(3, f)
@@ -221,6 +223,8 @@ class _NasBodyFunction(torch.autograd.Function):
                      frags[i].data_ptr(), tabs[i].data_ptr(), scal[i].data_ptr(), part_pw[i].data_ptr(), wgs, n, h, w, f, code, st())
             L.launch("sr_nas_dw_bwd", lib.sr_nas_dw_bwd, ys[i].data_ptr(), GZ.data_ptr(), g.data_ptr(), gin.data_ptr(),
                      dwp[i].data_ptr(), part_dw[i].data_ptr(), wgs, n, h, w, f, code, st())
+            L.launch("sr_nas_dw_wgrad", lib.sr_nas_dw_wgrad, ys[i].data_ptr(), GZ.data_ptr(), dwp[i].data_ptr(),
+                     part_dw[i].data_ptr(), wgs, n, h, w, f, code, st())
             g = gin
         spw, sdw = part_pw.sum(1), part_dw.sum(1)                                      # (nb, slab)
         g_wpw = spw.index_select(1, tb["g_wpw"]).view(nb, 3, f, f, 1, 1)
