@@ -69,10 +69,14 @@ __global__ __launch_bounds__(512) void nas_dw_fwd_kernel(const T* __restrict__ y
   typedef NasCfg<F> C;
   typedef typename FragOf<T>::type FragT;
   __shared__ __attribute__((aligned(16))) T X1[C::P3_ELEMS];
+  // stencil weights and biases in LDS: the per-tap wave-uniform s_load from HBM was the whole cost of this kernel
+  // (one dependent ~1 us round trip per tap); all lanes of a wave read the same address (LDS broadcast)
+  __shared__ __attribute__((aligned(16))) float WS[C::M1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.y, tile = blockIdx.x;
   const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
   const size_t img = (size_t)n * H * W * F;
+  for (int i = tid; i < C::M1; i += 512) WS[i] = dwp[i];
   nas_stage_halo3<T, C, 512>(X1, yin + img, dwp + C::M1, H, W, ty0, tx0, tid);
   __syncthreads();
   for (int item0 = wave; item0 < C::NITEM; item0 += 8) {
@@ -81,13 +85,13 @@ __global__ __launch_bounds__(512) void nas_dw_fwd_kernel(const T* __restrict__ y
     const int px = g * 64 + lane;
     const bool valid = px < C::NPXC;
     const int oy = valid ? px / C::TW : 0, ox = valid ? px % C::TW : 0;
-    const float* w = dwp + c * 8;                                   // wave-uniform
+    const float* w = WS + c * 8;                                    // wave-uniform
     float z3[8], z5[8], z7[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { z3[j] = w[C::BD + j]; z5[j] = w[C::BD + 32 + j]; z7[j] = w[C::BD + 64 + j]; }
 #pragma unroll 1
     for (int ty = 0; ty < 7; ++ty) {
-#pragma unroll 1
+#pragma unroll
       for (int tx = 0; tx < 7; ++tx) {
         const FragT v = *reinterpret_cast<const FragT*>(X1 + ((oy + ty) * C::PW + ox + tx) * F + c * 8);
         const bool in5 = ty >= 1 && ty <= 5 && tx >= 1 && tx <= 5, in3 = ty >= 2 && ty <= 4 && tx >= 2 && tx <= 4;
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(512) void nas_dw_bwd_kernel(const T* __restrict__ y
           const int px = g * 64 + lane;
           const bool valid = px < C::NPXC;
           const int oy = valid ? px / C::TW : 0, ox = valid ? px % C::TW : 0;
-          const float* w = dwp + wbase + c * 8;
+          const float* w = dwp + wbase + c * 8;              // wave-uniform scalar loads (LDS copies measured slower here)
           for (int ty = 0; ty < ks; ++ty) {
             for (int tx = 0; tx < ks; ++tx) {
               const FragT v = *reinterpret_cast<const FragT*>(GT + ((oy + off + ty) * C::PW + ox + off + tx) * F + c * 8);

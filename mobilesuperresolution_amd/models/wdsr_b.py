@@ -138,7 +138,7 @@ class _NasBlockFunction(torch.autograd.Function):
         tb = _nas_dev_tables(f, dev.index if dev.index is not None else torch.cuda.current_device())
         code = L.DTYPE_CODE[dt]
         gy = gy.contiguous()
-        wgs = 64
+        wgs = int(os.environ.get("SR_NAS_WGS", 256))
         GZ = torch.empty_like(V)
         part_pw = torch.empty((wgs, tb["pw_slab"]), dtype=torch.float32, device=dev)
         part_dw = torch.empty((wgs, tb["dw_slab"]), dtype=torch.float32, device=dev)
@@ -210,7 +210,7 @@ class _NasBodyFunction(torch.autograd.Function):
         dev, dt = ys.device, ys.dtype
         tb = _nas_dev_tables(f, dev.index if dev.index is not None else torch.cuda.current_device())
         code = L.DTYPE_CODE[dt]
-        wgs = 64
+        wgs = int(os.environ.get("SR_NAS_WGS", 256))
         GZ = torch.empty_like(V[0])
         part_pw = torch.empty((nb, wgs, tb["pw_slab"]), dtype=torch.float32, device=dev)
         part_dw = torch.empty((nb, wgs, tb["dw_slab"]), dtype=torch.float32, device=dev)
