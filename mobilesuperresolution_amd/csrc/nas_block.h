@@ -89,24 +89,26 @@ __global__ __launch_bounds__(512) void nas_dw_fwd_kernel(const T* __restrict__ y
     float z3[8], z5[8], z7[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { z3[j] = w[C::BD + j]; z5[j] = w[C::BD + 32 + j]; z7[j] = w[C::BD + 64 + j]; }
+    // one exact pass per stencil (no masked multiply-adds): rows one at a time, the taps of a row unrolled
+    auto stencil = [&](float (&z)[8], int ks, int wbase) {
+      const int off = 3 - ks / 2;
 #pragma unroll 1
-    for (int ty = 0; ty < 7; ++ty) {
+      for (int ty = 0; ty < ks; ++ty) {
+        const T* xr = X1 + ((oy + off + ty) * C::PW + ox + off) * F + c * 8;
+        const float* wr = w + wbase + ty * ks * 32;
 #pragma unroll
-      for (int tx = 0; tx < 7; ++tx) {
-        const FragT v = *reinterpret_cast<const FragT*>(X1 + ((oy + ty) * C::PW + ox + tx) * F + c * 8);
-        const bool in5 = ty >= 1 && ty <= 5 && tx >= 1 && tx <= 5, in3 = ty >= 2 && ty <= 4 && tx >= 2 && tx <= 4;
-        const float* w7 = w + C::W7 + (ty * 7 + tx) * 32;
-        const float* w5 = w + C::W5 + (in5 ? ((ty - 1) * 5 + tx - 1) * 32 : 0);
-        const float* w3 = w + C::W3 + (in3 ? ((ty - 2) * 3 + tx - 2) * 32 : 0);
+        for (int tx = 0; tx < 7; ++tx) {
+          if (tx < ks) {
+            const FragT v = *reinterpret_cast<const FragT*>(xr + tx * F);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float f = (float)v[j];
-          z7[j] += w7[j] * f;
-          z5[j] += in5 ? w5[j] * f : 0.f;
-          z3[j] += in3 ? w3[j] * f : 0.f;
+            for (int j = 0; j < 8; ++j) z[j] += wr[tx * 32 + j] * (float)v[j];
+          }
         }
       }
-    }
+    };
+    stencil(z7, 7, C::W7);
+    stencil(z5, 5, C::W5);
+    stencil(z3, 3, C::W3);
     const int Y = ty0 + oy, X = tx0 + ox;
     if (valid && Y < H && X < W) {
       const size_t o = img + ((size_t)Y * W + X) * F + c * 8;
@@ -372,7 +374,9 @@ __global__ __launch_bounds__(512) void nas_dw_bwd_kernel(const T* __restrict__ y
           const bool valid = px < C::NPXC;
           const int oy = valid ? px / C::TW : 0, ox = valid ? px % C::TW : 0;
           const float* w = dwp + wbase + c * 8;              // wave-uniform scalar loads (LDS copies measured slower here)
+#pragma unroll 1
           for (int ty = 0; ty < ks; ++ty) {
+#pragma unroll
             for (int tx = 0; tx < ks; ++tx) {
               const FragT v = *reinterpret_cast<const FragT*>(GT + ((oy + off + ty) * C::PW + ox + off + tx) * F + c * 8);
               const float* wt = w + ((ks - 1 - ty) * ks + (ks - 1 - tx)) * 32;
