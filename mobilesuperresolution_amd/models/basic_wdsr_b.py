@@ -106,7 +106,7 @@ class BASIC_MODEL(nn.Module):
                 "MI355X hot path supports num_channels=3, num_residual_units in {24,32}, scale in {2,3,4} "
                 f"(got {nin}, {f}, {self.scale}); there is no generic fallback")
         self.hot_dtype = _hot_dtype(params)
-        self.wgs_body = int(getattr(params, "hot_wgs_body", 16))
+        self.wgs_body = int(getattr(params, "hot_wgs_body", os.environ.get("SR_WGS_BODY", 16)))
         self.layout = get_layout(f, nb, self.scale)
         self.flat = nn.Parameter(self._reference_init())
         self._dev = {}
