@@ -221,9 +221,13 @@ typedef struct {
   void* tsave; void* dtsave;
 } sr_wdsr_net_t;
 
-/* weight-norm + packing + head + NB fused blocks + fused tail.  save_acts != 0 keeps every block input
- * (needed by sr_wdsr_net_backward); 0 ping-pongs between two slots (inference). */
-int sr_wdsr_net_forward(const sr_wdsr_net_t* net, int save_acts, sr_stream_t stream);
+/* weight-norm + packing + head + NB fused blocks + fused tail.  flags: SR_NET_SAVE_ACTS keeps every block input
+ * (needed by sr_wdsr_net_backward), otherwise two slots ping-pong (inference); SR_NET_WEIGHTS_PACKED skips the
+ * weight-norm + packing launches (the caller guarantees the packed blobs in `net` are those of `flat`, e.g. repeated
+ * inference with unchanged parameters). */
+#define SR_NET_SAVE_ACTS 1
+#define SR_NET_WEIGHTS_PACKED 2
+int sr_wdsr_net_forward(const sr_wdsr_net_t* net, int flags, sr_stream_t stream);
 /* full backward: d(loss)/d(out) -> gflat (gradient of every parameter in the flat buffer). */
 int sr_wdsr_net_backward(const sr_wdsr_net_t* net, sr_stream_t stream);
 

@@ -568,11 +568,13 @@ static size_t side_image_bytes(const sr_wdsr_net_t* n) {     // one block's [N][
   return (size_t)n->N * tiles * C::TH * C::TW * C::LP * 2;
 }
 
-extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int save_acts, sr_stream_t stream) {
+extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int flags, sr_stream_t stream) {
   if (!n || !n->flat || !n->src || !n->x || !n->acts || !n->out) return -2;
   hipStream_t st = (hipStream_t)stream;
   const size_t esz = n->dtype == SR_DTYPE_BF16 ? 2 : 4;
-  int rc = n->dtype == SR_DTYPE_BF16 ? net_pack<__bf16>(n, st) : net_pack<float>(n, st);
+  const int save_acts = flags & SR_NET_SAVE_ACTS;
+  int rc = 0;
+  if (!(flags & SR_NET_WEIGHTS_PACKED)) rc = n->dtype == SR_DTYPE_BF16 ? net_pack<__bf16>(n, st) : net_pack<float>(n, st);
   if (rc) return rc;
   const size_t act = (size_t)n->N * n->H * n->W * n->F * esz;
   const size_t blob = (size_t)n->n_idx_body * esz;

@@ -286,3 +286,22 @@ def test_saved_image_weight_gradients_equal_recompute_path(shape, monkeypatch):
     assert scale > 0 and torch.isfinite(g_saved).all()
     assert float((g_saved - g_rec).abs().max()) <= 2e-3 * scale
     assert float((g_saved - g_rec).abs().mean()) <= 2e-6 * scale
+
+
+@pytest.mark.gpu
+def test_static_weights_inference_skips_prep_and_matches():
+    """opt-in `assume_static_weights`: repeated inference re-uses the packed weights (SR_NET_WEIGHTS_PACKED) and gives
+    the same output; a parameter update (version bump) re-packs"""
+    torch.manual_seed(9)
+    m = _model(_ns(num_blocks=2, hot_dtype="bf16")).eval()
+    x = torch.rand(2, 3, 20, 28, device="cuda")
+    with torch.no_grad():
+        ref = m(x)
+        m.assume_static_weights = True
+        a, b = m(x), m(x)
+        assert torch.equal(a, ref) and torch.equal(b, ref)
+        m.flat.mul_(1.01)                                    # in-place update through the parameter: version bump
+        c = m(x)
+        m.assume_static_weights = False
+        d = m(x)
+    assert torch.equal(c, d) and not torch.equal(c, ref)
