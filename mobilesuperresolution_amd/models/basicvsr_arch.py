@@ -185,7 +185,9 @@ class _TrunkFunction(torch.autograd.Function):
                 ci0, L.DTYPE_CODE[dt])
         ctx.mod, ctx.x0, ctx.acts, ctx.mids, ctx.blob = mod, x0, acts, mids, blob
         ctx.need_dx = fea.requires_grad
-        return acts[nb].permute(0, 3, 1, 2).float().contiguous()
+        out = torch.empty((n, 24, h, w), dtype=torch.float32, device=dev)
+        out.copy_(acts[nb].permute(0, 3, 1, 2))                 # NHWC hot dtype -> NCHW fp32 in one kernel
+        return out
 
     @staticmethod
     def backward(ctx, dy):
@@ -203,7 +205,10 @@ class _TrunkFunction(torch.autograd.Function):
         _launch("sr_c3_trunk_bwd", x0.data_ptr(), acts.data_ptr(), mids.data_ptr(), ga.data_ptr(), gt.data_ptr(),
                 blob.data_ptr(), boff, parts.data_ptr(), dx0.data_ptr() if dx0 is not None else None, nb, wgs, n, h, w, ci0,
                 L.DTYPE_CODE[dt])
-        dfea = dx0[..., :cin].permute(0, 3, 1, 2).float().contiguous() if dx0 is not None else None
+        dfea = None
+        if dx0 is not None:
+            dfea = torch.empty((n, cin, h, w), dtype=torch.float32, device=dev)
+            dfea.copy_(dx0[..., :cin].permute(0, 3, 1, 2))
         gflat = parts.sum(1).reshape(-1).index_select(0, grad_idx)                   # dW | db of every conv, flat order
         return dfea, None, gflat
 
