@@ -217,7 +217,7 @@ typedef struct {
   /* activations: x NCHW fp32; acts/grads [(NB+1)][N][H][W][F] (acts may be 2 ping-pong slots when
    * save_acts == 0); out / dout NCHW fp32 [N][3][R*H][R*W] */
   const float* x; void* acts; void* grads; float* out; const float* dout;
-  /* optional (bf16, F = 24, even NB; NULL = recompute in backward): t and dt of every block, [NB][N][tiles][288][24] */
+  /* optional (bf16, F = 24; NULL = recompute in backward): t and dt of every block, [NB][N][tiles][288][24] */
   void* tsave; void* dtsave;
 } sr_wdsr_net_t;
 

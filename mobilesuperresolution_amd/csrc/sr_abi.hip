@@ -15,24 +15,24 @@ namespace {
 
 template <typename T, int F, int E, int L>
 int launch_block_fwd(const void* x, void* y, const void* wblob, const float* cinit, int N, int H, int W,
-                     hipStream_t st, unsigned long long* stamps = nullptr) {
+                     hipStream_t st, unsigned long long* stamps = nullptr, void* tsave = nullptr) {
   typedef BlockCfg<F, E, L> C;
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
   dim3 grid(tiles_x * tiles_y, N), block(64 * C::NPT_H);
   hipLaunchKernelGGL((wdsr_block_fwd_kernel<T, F, E, L>), grid, block, 0, st, (const T*)x, (T*)y, (const T*)wblob,
-                     cinit, H, W, tiles_x, stamps);
+                     cinit, H, W, tiles_x, stamps, (T*)tsave);
   SR_HIP_CHECK_LAUNCH();
   return 0;
 }
 
 template <typename T, int F, int E, int L>
 int launch_block_bwd_data(const void* x, const void* dy, void* dx, const void* wblob, const float* cinit, int N,
-                          int H, int W, hipStream_t st) {
+                          int H, int W, hipStream_t st, void* dtsave = nullptr) {
   typedef BlockCfg<F, E, L> C;
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
   dim3 grid(tiles_x * tiles_y, N), block(64 * C::NPT_O);
   hipLaunchKernelGGL((wdsr_block_bwd_data_kernel<T, F, E, L>), grid, block, 0, st, (const T*)x, (const T*)dy, (T*)dx,
-                     (const T*)wblob, cinit, H, W, tiles_x);
+                     (const T*)wblob, cinit, H, W, tiles_x, (T*)dtsave);
   SR_HIP_CHECK_LAUNCH();
   return 0;
 }
@@ -560,7 +560,15 @@ template <typename T> int net_pack(const sr_wdsr_net_t* n, hipStream_t st) {
 // t / dt of every block are kept for the weight-gradient kernels when every block runs through the
 // two-block kernels (bf16, F = 24, even block count) and the caller provided both buffers
 static bool net_saves_side_images(const sr_wdsr_net_t* n, bool backward) {
-  return n->F == 24 && n->dtype == SR_DTYPE_BF16 && (n->NB % 2) == 0 && n->tsave && (!backward || n->dtsave);
+  return n->F == 24 && n->dtype == SR_DTYPE_BF16 && n->tsave && (!backward || n->dtsave);
+}
+// Two blocks per launch pay while a launch is bound by its fixed costs (about one workgroup per CU); with more
+// workgroups the single-block kernels win (two resident per CU, no halo-2 recompute): measured crossover at
+// batch 64 of 48x48 patches = 512 workgroups (tools/bench_rows.py).
+static bool net_uses_pairs(const sr_wdsr_net_t* n) {
+  typedef BlockCfg<24, 144, 20> C;
+  const long wgs = (long)n->N * ((n->W + C::TW - 1) / C::TW) * ((n->H + C::TH - 1) / C::TH);
+  return n->F == 24 && n->dtype == SR_DTYPE_BF16 && wgs <= 384;
 }
 static size_t side_image_bytes(const sr_wdsr_net_t* n) {     // one block's [N][tiles][288][LP] image
   typedef BlockCfg<24, 144, 20> C;
@@ -581,7 +589,7 @@ extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int flags, sr_stream_
   char* acts = (char*)n->acts;
   if ((rc = sr_head_fwd(n->x, acts, n->blob_head, n->mean, n->N, n->H, n->W, n->F, n->dtype, stream))) return rc;
   char* cur = acts;
-  const bool pairs = n->F == 24 && n->dtype == SR_DTYPE_BF16;   // two blocks per launch
+  const bool pairs = net_uses_pairs(n);
   const bool saved = net_saves_side_images(n, false);
   const size_t side = side_image_bytes(n);
   for (int i = 0; i < n->NB; ++i) {
@@ -599,8 +607,13 @@ extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int flags, sr_stream_
       continue;
     }
     char* nxt = save_acts ? acts + (size_t)(i + 1) * act : (cur == acts ? acts + act : acts);
-    if ((rc = sr_wdsr_block_fwd(cur, nxt, (char*)n->blob_body + i * blob, n->cinit_body + (size_t)i * n->n_idx_cinit,
-                                n->N, n->H, n->W, n->F, n->dtype, stream)))
+    if (save_acts && saved) {                     // single-block kernel that also keeps t (bf16, F = 24)
+      if ((rc = launch_block_fwd<__bf16, 24, 144, 20>(cur, nxt, (char*)n->blob_body + i * blob,
+                                                      n->cinit_body + (size_t)i * n->n_idx_cinit, n->N, n->H, n->W, st,
+                                                      nullptr, (char*)n->tsave + (size_t)i * side)))
+        return rc;
+    } else if ((rc = sr_wdsr_block_fwd(cur, nxt, (char*)n->blob_body + i * blob,
+                                       n->cinit_body + (size_t)i * n->n_idx_cinit, n->N, n->H, n->W, n->F, n->dtype, stream)))
       return rc;
     cur = nxt;
   }
@@ -629,7 +642,7 @@ extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) 
                             n->W, n->F, n->R, n->dtype, stream)))
       return rc;
   }
-  const bool pairs = n->F == 24 && n->dtype == SR_DTYPE_BF16;   // two blocks per launch
+  const bool pairs = net_uses_pairs(n);
   const bool saved = net_saves_side_images(n, true);
   const size_t side = side_image_bytes(n);
   for (int i = n->NB - 1; i >= 0; --i) {
@@ -646,9 +659,15 @@ extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) 
       --i;
       continue;
     }
-    if ((rc = sr_wdsr_block_bwd_data(acts + (size_t)i * act, grads + (size_t)(i + 1) * act, grads + (size_t)i * act,
-                                     (char*)n->blob_body + i * blob, n->cinit_body + (size_t)i * n->n_idx_cinit, n->N,
-                                     n->H, n->W, n->F, n->dtype, stream)))
+    if (saved) {
+      if ((rc = launch_block_bwd_data<__bf16, 24, 144, 20>(acts + (size_t)i * act, grads + (size_t)(i + 1) * act,
+                                                           grads + (size_t)i * act, (char*)n->blob_body + i * blob,
+                                                           n->cinit_body + (size_t)i * n->n_idx_cinit, n->N, n->H, n->W,
+                                                           (hipStream_t)stream, (char*)n->dtsave + (size_t)i * side)))
+        return rc;
+    } else if ((rc = sr_wdsr_block_bwd_data(acts + (size_t)i * act, grads + (size_t)(i + 1) * act, grads + (size_t)i * act,
+                                            (char*)n->blob_body + i * blob, n->cinit_body + (size_t)i * n->n_idx_cinit,
+                                            n->N, n->H, n->W, n->F, n->dtype, stream)))
       return rc;
   }
   if (saved) {

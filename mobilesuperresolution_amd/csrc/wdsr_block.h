@@ -69,7 +69,8 @@ SR_DEV void stage_x_halo(T* Xs, const T* __restrict__ xin, int H, int W, int ty0
 template <typename T, int F, int E, int L>
 __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block_fwd_kernel(
     const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ wblob,
-    const float* __restrict__ cinit, int H, int W, int tiles_x, unsigned long long* __restrict__ stamps) {
+    const float* __restrict__ cinit, int H, int W, int tiles_x, unsigned long long* __restrict__ stamps,
+    T* __restrict__ tsave) {
   typedef BlockCfg<F, E, L> C;
   typedef typename FragOf<T>::type FragT;
   typedef typename FragOf<T>::half_type HalfT;
@@ -131,6 +132,12 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block_fw
         for (int j = 0; j < 4; ++j) v[j] = (T)0.f;
       }
       *reinterpret_cast<HalfT*>(Ts + hp * C::LP + g * 8 + hh * 4) = v;
+      if (tsave && hp < C::NPXH) {               // keep t of the core pixels for sr_wdsr_block_wgrad_saved (tile-local layout)
+        const int hy = hp / C::HW, hx = hp - hy * C::HW;
+        if (hy >= 1 && hy <= C::TH && hx >= 1 && hx <= C::TW)
+          stream_store(reinterpret_cast<HalfT*>(tsave + (((size_t)n * gridDim.x + tile) * (C::TH * C::TW) + (hy - 1) * C::TW + hx - 1) * C::LP +
+                                                g * 8 + hh * 4), v);
+      }
     }
   }
   SR_STAMP(3);
@@ -328,7 +335,7 @@ SR_DEV f32x16 dt_tile(const T* DYs, const WS& wsrc, int w3t_base, int hbase, int
 template <typename T, int F, int E, int L>
 __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_O)) void wdsr_block_bwd_data_kernel(
     const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, const T* __restrict__ wblob,
-    const float* __restrict__ cinit, int H, int W, int tiles_x) {
+    const float* __restrict__ cinit, int H, int W, int tiles_x, T* __restrict__ dtsave) {
   typedef BlockCfg<F, E, L> C;
   typedef BwdCfg<C> B;
   typedef typename FragOf<T>::type FragT;
@@ -364,6 +371,19 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_O)) void wdsr_block_bw
     const int oy = (ot / (C::TW / 8)) * 4 + (r >> 3), ox = (ot % (C::TW / 8)) * 8 + (r & 7);
     const int hbase = oy * C::HW + ox, pc = oy * C::TW + ox;
     const f32x16 dtacc = dt_tile<T, C>(DYs, wsrc, LW3T, hbase, lane);
+    if (dtsave) {                                  // keep dt of the core pixels (zero outside the image)
+      const bool inimg = (ty0 + oy < H) && (tx0 + ox < W);
+      T* o = dtsave + (((size_t)n * gridDim.x + tile) * B::NPXC + pc) * C::LP;
+#pragma unroll
+      for (int g = 0; g < C::CPT; ++g) {
+        HalfT v = acc_group<T>(dtacc, g);
+        if (!inimg) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (T)0.f;
+        }
+        stream_store(reinterpret_cast<HalfT*>(o + g * 8 + hh * 4), v);
+      }
+    }
     const FragT dtb0 = acc_to_frag<T, 0>(dtacc), dtb1 = acc_to_frag<T, 1>(dtacc);
     FragT xb[C::KS1];
 #pragma unroll

@@ -202,10 +202,10 @@ class BASIC_MODEL(nn.Module):
         return out, acts, side
 
     def _saves_side_images(self) -> bool:
-        """bf16 / 24 units / even block count: the two-block kernels keep t (forward) and dt (backward) of every
-        block so the weight-gradient kernels need not recompute them (csrc/wdsr_block.h)."""
+        """bf16 / 24 units: the forward / backward-data kernels keep t and dt of every block so the weight-gradient
+        kernels need not recompute them (csrc/wdsr_block.h)."""
         lay = self.layout
-        return (self.hot_dtype == torch.bfloat16 and lay.F == 24 and lay.NB % 2 == 0 and lay.NB > 0
+        return (self.hot_dtype == torch.bfloat16 and lay.F == 24 and lay.NB > 0
                 and os.environ.get("SR_RECOMPUTE_WGRAD", "0") != "1")
 
     def _side_shape(self, n, h, w):
