@@ -58,13 +58,13 @@ int sr_wdsr_block2_bwd_data(const void* xa, const void* xb, const void* dyb, voi
                             void* dtsave_a, void* dtsave_b, int N, int H, int W, int F, int dtype, sr_stream_t stream);
 /* dtsave_a / dtsave_b (NULL = off): keep each block's dt = conv3x3^T(dy), same layout as tsave.
  *
- * Weight gradients of `layers` blocks from the saved t / dt images instead of recomputing them (bf16,
- * F = 24 only; -1 otherwise).  Same slabs as sr_wdsr_block_wgrad.  side_ls = elements between two blocks'
- * saved images. */
+ * Weight gradients of `layers` blocks from the saved t / dt images instead of recomputing them (bf16 only;
+ * -1 otherwise).  Same slabs as sr_wdsr_block_wgrad.  side_ls = elements between two blocks' saved images
+ * ([N][tiles][288][LP], LP = 24 for 24 units, 32 for 32 units). */
 int sr_wdsr_block_wgrad_saved(const void* x, const void* dy, const void* tsave, const void* dtsave,
-                              const void* wblob, float* partial_a, float* partial_b, int layers, int wgs, int N,
-                              int H, int W, int F, int dtype, long x_ls, long dy_ls, long side_ls, long w_ls,
-                              sr_stream_t stream);
+                              const void* wblob, const float* cinit, float* partial_a, float* partial_b, int layers,
+                              int wgs, int N, int H, int W, int F, int dtype, long x_ls, long dy_ls, long side_ls,
+                              long w_ls, long c_ls, sr_stream_t stream);
 
 /* Measurement aid for bench.py's roofline leg: `reps` back-to-back launches of the same forward kernel,
  * ping-ponging x <-> y, so that HIP events around the call measure the kernel and not the host. */
@@ -217,7 +217,7 @@ typedef struct {
   /* activations: x NCHW fp32; acts/grads [(NB+1)][N][H][W][F] (acts may be 2 ping-pong slots when
    * save_acts == 0); out / dout NCHW fp32 [N][3][R*H][R*W] */
   const float* x; void* acts; void* grads; float* out; const float* dout;
-  /* optional (bf16, F = 24; NULL = recompute in backward): t and dt of every block, [NB][N][tiles][288][24] */
+  /* optional (bf16; NULL = recompute in backward): t and dt of every block, [NB][N][tiles][288][LP] */
   void* tsave; void* dtsave;
 } sr_wdsr_net_t;
 

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsr_hotpath.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
 
 _P, _I, _Z, _L, _F = c_void_p, c_int, c_size_t, ctypes.c_long, ctypes.c_float
@@ -19,7 +19,7 @@ SIGNATURES = {
     "sr_abi_version": ([], _I),
     "sr_wdsr_block_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block2_fwd": ([_P] * 9 + [_I] * 5 + [_P], _I),
-    "sr_wdsr_block_wgrad_saved": ([_P] * 7 + [_I] * 7 + [_L] * 4 + [_P], _I),
+    "sr_wdsr_block_wgrad_saved": ([_P] * 8 + [_I] * 7 + [_L] * 5 + [_P], _I),
     "sr_wdsr_block2_bwd_data": ([_P] * 11 + [_I] * 5 + [_P], _I),
     "sr_wdsr_block2_fwd_repeat": ([_P] * 7 + [_I] * 6 + [_P], _I),
     "sr_probe_launch_floor": ([_P, _I, _I, _I, _I, _I, _P], _I),

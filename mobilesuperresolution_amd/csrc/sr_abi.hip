@@ -9,7 +9,7 @@
 #include "nas_block.h"
 #include "flow_warp.h"
 
-extern "C" int sr_abi_version(void) { return 2; }
+extern "C" int sr_abi_version(void) { return 3; }
 
 namespace {
 
@@ -144,26 +144,38 @@ extern "C" int sr_wdsr_block_wgrad(const void* x, const void* dy, const void* wb
   return -1;
 }
 
-extern "C" int sr_wdsr_block_wgrad_saved(const void* x, const void* dy, const void* tsave, const void* dtsave,
-                                         const void* wblob, float* pa, float* pb, int layers, int wgs, int N, int H,
-                                         int W, int F, int dtype, long x_ls, long dy_ls, long side_ls, long w_ls,
-                                         sr_stream_t stream) {
-  if (!x || !dy || !tsave || !dtsave || !wblob || !pa || !pb || layers <= 0 || wgs <= 0 || N <= 0 || H <= 0 || W <= 0 ||
-      layers > 65535)
-    return -2;
-  if (F != 24 || dtype != SR_DTYPE_BF16) return -1;
-  typedef BlockCfg<24, 144, 20> C;
+namespace {
+template <int F, int E, int L>
+int launch_wgrad_saved(const void* x, const void* dy, const void* tsave, const void* dtsave, const void* wblob,
+                       const float* cinit, float* pa, float* pb, int layers, int wgs, int N, int H, int W, long x_ls,
+                       long dy_ls, long side_ls, long w_ls, long c_ls, hipStream_t st) {
+  typedef BlockCfg<F, E, L> C;
+  typedef __bf16 T;
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
   dim3 grid(wgs, layers);
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL((wdsr_block_wgrad_saved_kernel<__bf16, 24, 144, 20, 0>), grid, dim3(64 * WgradSavedCfg<24, 144, 20, 0>::NWAVES),
-                     0, st, (const __bf16*)x, (const __bf16*)dtsave, (const __bf16*)wblob, pa, N, H, W, tiles_x,
-                     tiles_x * tiles_y, x_ls, side_ls, w_ls);
-  hipLaunchKernelGGL((wdsr_block_wgrad_saved_kernel<__bf16, 24, 144, 20, 1>), grid, dim3(64 * WgradSavedCfg<24, 144, 20, 1>::NWAVES),
-                     0, st, (const __bf16*)dy, (const __bf16*)tsave, (const __bf16*)wblob, pb, N, H, W, tiles_x,
-                     tiles_x * tiles_y, dy_ls, side_ls, w_ls);
+  hipLaunchKernelGGL((wdsr_block_wgrad_saved_kernel<T, F, E, L, 0>), grid, dim3(64 * WgradSavedCfg<F, E, L, 0>::NWAVES), 0, st,
+                     (const T*)x, (const T*)dtsave, (const T*)wblob, cinit, pa, N, H, W, tiles_x, tiles_x * tiles_y, x_ls,
+                     side_ls, w_ls, c_ls);
+  hipLaunchKernelGGL((wdsr_block_wgrad_saved_kernel<T, F, E, L, 1>), grid, dim3(64 * WgradSavedCfg<F, E, L, 1>::NWAVES), 0, st,
+                     (const T*)dy, (const T*)tsave, (const T*)wblob, cinit, pb, N, H, W, tiles_x, tiles_x * tiles_y, dy_ls,
+                     side_ls, w_ls, c_ls);
   SR_HIP_CHECK_LAUNCH();
   return 0;
+}
+}  // namespace
+
+extern "C" int sr_wdsr_block_wgrad_saved(const void* x, const void* dy, const void* tsave, const void* dtsave,
+                                         const void* wblob, const float* cinit, float* pa, float* pb, int layers, int wgs,
+                                         int N, int H, int W, int F, int dtype, long x_ls, long dy_ls, long side_ls,
+                                         long w_ls, long c_ls, sr_stream_t stream) {
+  if (!x || !dy || !tsave || !dtsave || !wblob || !cinit || !pa || !pb || layers <= 0 || wgs <= 0 || N <= 0 || H <= 0 ||
+      W <= 0 || layers > 65535)
+    return -2;
+  if (dtype != SR_DTYPE_BF16) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  if (F == 24) return launch_wgrad_saved<24, 144, 20>(x, dy, tsave, dtsave, wblob, cinit, pa, pb, layers, wgs, N, H, W, x_ls, dy_ls, side_ls, w_ls, c_ls, st);
+  if (F == 32) return launch_wgrad_saved<32, 192, 26>(x, dy, tsave, dtsave, wblob, cinit, pa, pb, layers, wgs, N, H, W, x_ls, dy_ls, side_ls, w_ls, c_ls, st);
+  return -1;
 }
 
 extern "C" int sr_wdsr_block_wgrad_stamps(const void* x, const void* dy, const void* wblob, const float* cinit,
@@ -560,7 +572,7 @@ template <typename T> int net_pack(const sr_wdsr_net_t* n, hipStream_t st) {
 // t / dt of every block are kept for the weight-gradient kernels when every block runs through the
 // two-block kernels (bf16, F = 24, even block count) and the caller provided both buffers
 static bool net_saves_side_images(const sr_wdsr_net_t* n, bool backward) {
-  return n->F == 24 && n->dtype == SR_DTYPE_BF16 && n->tsave && (!backward || n->dtsave);
+  return (n->F == 24 || n->F == 32) && n->dtype == SR_DTYPE_BF16 && n->tsave && (!backward || n->dtsave);
 }
 // Two blocks per launch pay while a launch is bound by its fixed costs (about one workgroup per CU); with more
 // workgroups the single-block kernels win (two resident per CU, no halo-2 recompute): measured crossover at
@@ -573,7 +585,8 @@ static bool net_uses_pairs(const sr_wdsr_net_t* n) {
 static size_t side_image_bytes(const sr_wdsr_net_t* n) {     // one block's [N][tiles][288][LP] image
   typedef BlockCfg<24, 144, 20> C;
   const size_t tiles = (size_t)((n->W + C::TW - 1) / C::TW) * ((n->H + C::TH - 1) / C::TH);
-  return (size_t)n->N * tiles * C::TH * C::TW * C::LP * 2;
+  const int lp = n->F == 24 ? BlockCfg<24, 144, 20>::LP : BlockCfg<32, 192, 26>::LP;
+  return (size_t)n->N * tiles * C::TH * C::TW * lp * 2;
 }
 
 extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int flags, sr_stream_t stream) {
@@ -607,11 +620,14 @@ extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int flags, sr_stream_
       continue;
     }
     char* nxt = save_acts ? acts + (size_t)(i + 1) * act : (cur == acts ? acts + act : acts);
-    if (save_acts && saved) {                     // single-block kernel that also keeps t (bf16, F = 24)
-      if ((rc = launch_block_fwd<__bf16, 24, 144, 20>(cur, nxt, (char*)n->blob_body + i * blob,
-                                                      n->cinit_body + (size_t)i * n->n_idx_cinit, n->N, n->H, n->W, st,
-                                                      nullptr, (char*)n->tsave + (size_t)i * side)))
-        return rc;
+    if (save_acts && saved) {                     // single-block kernel that also keeps t (bf16)
+      rc = n->F == 24 ? launch_block_fwd<__bf16, 24, 144, 20>(cur, nxt, (char*)n->blob_body + i * blob,
+                                                              n->cinit_body + (size_t)i * n->n_idx_cinit, n->N, n->H, n->W,
+                                                              st, nullptr, (char*)n->tsave + (size_t)i * side)
+                      : launch_block_fwd<__bf16, 32, 192, 26>(cur, nxt, (char*)n->blob_body + i * blob,
+                                                              n->cinit_body + (size_t)i * n->n_idx_cinit, n->N, n->H, n->W,
+                                                              st, nullptr, (char*)n->tsave + (size_t)i * side);
+      if (rc) return rc;
     } else if ((rc = sr_wdsr_block_fwd(cur, nxt, (char*)n->blob_body + i * blob,
                                        n->cinit_body + (size_t)i * n->n_idx_cinit, n->N, n->H, n->W, n->F, n->dtype, stream)))
       return rc;
@@ -660,20 +676,25 @@ extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) 
       continue;
     }
     if (saved) {
-      if ((rc = launch_block_bwd_data<__bf16, 24, 144, 20>(acts + (size_t)i * act, grads + (size_t)(i + 1) * act,
-                                                           grads + (size_t)i * act, (char*)n->blob_body + i * blob,
-                                                           n->cinit_body + (size_t)i * n->n_idx_cinit, n->N, n->H, n->W,
-                                                           (hipStream_t)stream, (char*)n->dtsave + (size_t)i * side)))
-        return rc;
+      rc = n->F == 24
+               ? launch_block_bwd_data<__bf16, 24, 144, 20>(acts + (size_t)i * act, grads + (size_t)(i + 1) * act,
+                                                            grads + (size_t)i * act, (char*)n->blob_body + i * blob,
+                                                            n->cinit_body + (size_t)i * n->n_idx_cinit, n->N, n->H, n->W,
+                                                            (hipStream_t)stream, (char*)n->dtsave + (size_t)i * side)
+               : launch_block_bwd_data<__bf16, 32, 192, 26>(acts + (size_t)i * act, grads + (size_t)(i + 1) * act,
+                                                            grads + (size_t)i * act, (char*)n->blob_body + i * blob,
+                                                            n->cinit_body + (size_t)i * n->n_idx_cinit, n->N, n->H, n->W,
+                                                            (hipStream_t)stream, (char*)n->dtsave + (size_t)i * side);
+      if (rc) return rc;
     } else if ((rc = sr_wdsr_block_bwd_data(acts + (size_t)i * act, grads + (size_t)(i + 1) * act, grads + (size_t)i * act,
                                             (char*)n->blob_body + i * blob, n->cinit_body + (size_t)i * n->n_idx_cinit,
                                             n->N, n->H, n->W, n->F, n->dtype, stream)))
       return rc;
   }
   if (saved) {
-    if ((rc = sr_wdsr_block_wgrad_saved(acts, grads + act, n->tsave, n->dtsave, n->blob_body, n->part_a, n->part_b, n->NB,
-                                        n->wgs_body, n->N, n->H, n->W, n->F, n->dtype, act_e, act_e,
-                                        (long)(side / esz), (long)n->n_idx_body, stream)))
+    if ((rc = sr_wdsr_block_wgrad_saved(acts, grads + act, n->tsave, n->dtsave, n->blob_body, n->cinit_body, n->part_a,
+                                        n->part_b, n->NB, n->wgs_body, n->N, n->H, n->W, n->F, n->dtype, act_e, act_e,
+                                        (long)(side / esz), (long)n->n_idx_body, (long)n->n_idx_cinit, stream)))
       return rc;
   } else if ((rc = sr_wdsr_block_wgrad(acts, grads + act, n->blob_body, n->cinit_body, n->part_a, n->part_b, n->NB,
                                        n->wgs_body, n->N, n->H, n->W, n->F, n->dtype, act_e, act_e, (long)n->n_idx_body,

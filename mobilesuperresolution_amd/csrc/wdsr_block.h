@@ -1125,19 +1125,21 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block2_b
 // Slab layouts are those of wdsr_block_wgrad_kernel.
 // =============================================================================================
 template <int F, int E, int L, int ROLE> struct WgradSavedCfg {
-  static constexpr int NSPLIT = 3;                  // ROLE 0: waves per e-tile (each takes every NSPLIT-th pixel tile)
+  // ROLE 0: waves per e-tile (each takes every NSPLIT-th pixel tile); 32 units: 6 e-tiles, two partial slabs fit LDS
+  static constexpr int NSPLIT = BlockCfg<F, E, L>::NET <= 5 ? 3 : 2;
   static constexpr int NWAVES = ROLE == 0 ? NSPLIT * BlockCfg<F, E, L>::NET : 9;
 };
 
 template <typename T, int F, int E, int L, int ROLE>
 __global__ __launch_bounds__((64 * WgradSavedCfg<F, E, L, ROLE>::NWAVES)) void wdsr_block_wgrad_saved_kernel(
-    const T* __restrict__ act, const T* __restrict__ side, const T* __restrict__ wblob, float* __restrict__ partial,
-    int N, int H, int W, int tiles_x, int tiles_per_img, long act_ls, long side_ls, long w_ls) {
+    const T* __restrict__ act, const T* __restrict__ side, const T* __restrict__ wblob, const float* __restrict__ cinit,
+    float* __restrict__ partial, int N, int H, int W, int tiles_x, int tiles_per_img, long act_ls, long side_ls, long w_ls,
+    long c_ls) {
   typedef BlockCfg<F, E, L> C;
   typedef BwdCfg<C> B;
   typedef WgradSavedCfg<F, E, L, ROLE> G;
   typedef typename FragOf<T>::type FragT;
-  static_assert(sizeof(T) == 2 && C::FOLD_B1, "saved-image weight gradients: bf16, bias folded through the ones channel");
+  static_assert(sizeof(T) == 2, "saved-image weight gradients: bf16");
   constexpr int NTHREADS = 64 * G::NWAVES;
   constexpr int IMG_ELEMS = (B::NPXC + 1) * 32;                       // dt or t image: [core px][32 ch]
   constexpr int ACT_ELEMS = ROLE == 0 ? B::XC_ELEMS : B::DY_ELEMS;     // x core tile / dy halo tile
@@ -1159,6 +1161,8 @@ __global__ __launch_bounds__((64 * WgradSavedCfg<F, E, L, ROLE>::NWAVES)) void w
   act += (size_t)layer * act_ls;
   side += (size_t)layer * side_ls;
   WSrc<T, true> wsrc;
+  float b1n[ROLE == 0 && !C::FOLD_B1 ? 1 : 1] = {0.f};      // conv1 bias of this lane's e column (32 units: not folded)
+  if constexpr (ROLE == 0 && !C::FOLD_B1) b1n[0] = cinit[(size_t)layer * c_ls + B::B1N_OFF + (wave / G::NSPLIT) * 32 + r];
   if constexpr (ROLE == 0) {
     wblob += (size_t)layer * w_ls;
     T* wl = BUF + 2 * TILE_ELEMS;
@@ -1244,7 +1248,9 @@ __global__ __launch_bounds__((64 * WgradSavedCfg<F, E, L, ROLE>::NWAVES)) void w
         const int pc = (toy + (r >> 3)) * C::TW + tox + (r & 7);
         auto rowx = [=](int p) { return ((toy + (p >> 3)) * C::TW + tox + (p & 7)) * C::KX; };
         auto rowi = [=](int p) { return ((toy + (p >> 3)) * C::TW + tox + (p & 7)) * 32; };
-        f32x16 h2 = zero16();
+        f32x16 h2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) h2[i] = b1n[0];
 #pragma unroll
         for (int s = 0; s < C::KS1; ++s)
           h2 = mma16<T>(lds_chunk<T>(XC, pc * C::KX + (2 * s + hh) * 8), wsrc.get(C::W1_OFF + et * C::KS1 + s, lane), h2);

@@ -202,15 +202,14 @@ class BASIC_MODEL(nn.Module):
         return out, acts, side
 
     def _saves_side_images(self) -> bool:
-        """bf16 / 24 units: the forward / backward-data kernels keep t and dt of every block so the weight-gradient
+        """bf16: the forward / backward-data kernels keep t and dt of every block so the weight-gradient
         kernels need not recompute them (csrc/wdsr_block.h)."""
         lay = self.layout
-        return (self.hot_dtype == torch.bfloat16 and lay.F == 24 and lay.NB > 0
-                and os.environ.get("SR_RECOMPUTE_WGRAD", "0") != "1")
+        return (self.hot_dtype == torch.bfloat16 and lay.NB > 0 and os.environ.get("SR_RECOMPUTE_WGRAD", "0") != "1")
 
     def _side_shape(self, n, h, w):
         tiles = ((h + 11) // 12) * ((w + 23) // 24)
-        return (self.layout.NB, n, tiles, 288, 24)
+        return (self.layout.NB, n, tiles, 288, 24 if self.layout.F == 24 else 32)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._check_input(x)

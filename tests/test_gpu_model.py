@@ -260,16 +260,17 @@ def test_linearity_of_backward_at_full_size():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,nb", [((3, 3, 48, 48), 4), ((2, 3, 20, 28), 4), ((1, 3, 7, 9), 4),
-                                      ((3, 3, 48, 48), 3),          # odd block count: two-block launch + one single
-                                      ((50, 3, 48, 48), 2)])        # 400 workgroups: the single-block kernels (with saves)
-def test_saved_image_weight_gradients_equal_recompute_path(shape, nb, monkeypatch):
+@pytest.mark.parametrize("shape,nb,units", [((3, 3, 48, 48), 4, 24), ((2, 3, 20, 28), 4, 24), ((1, 3, 7, 9), 4, 24),
+                                            ((3, 3, 48, 48), 3, 24),      # odd block count: two-block launch + one single
+                                            ((50, 3, 48, 48), 2, 24),     # 400 workgroups: single-block kernels (with saves)
+                                            ((3, 3, 48, 48), 3, 32), ((2, 3, 20, 28), 2, 32)])   # 32 units (C3 width)
+def test_saved_image_weight_gradients_equal_recompute_path(shape, nb, units, monkeypatch):
     """bf16 / 24 units: the weight-gradient kernels fed by the saved t / dt images (two-block kernels) give the
     gradients of the recompute kernels: the same bf16 products, summed over pixel tiles in a different fp32 order
     (3 partial sums per e-tile instead of 2); db2 is the pixel sum of the bf16-rounded dt image instead of the
     fp32 accumulators (a bf16-rounding-level difference on the 20 conv2 biases per block)."""
     torch.manual_seed(5)
-    m = _model(_ns(num_blocks=nb, hot_dtype="bf16")).train()
+    m = _model(_ns(num_blocks=nb, num_residual_units=units, hot_dtype="bf16")).train()
     with torch.no_grad():
         m.flat.add_(0.02 * torch.randn_like(m.flat))
     x = torch.rand(*shape, device="cuda")
