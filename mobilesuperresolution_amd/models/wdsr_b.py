@@ -463,52 +463,71 @@ class NAS_MODEL(nn.Module):
         out = _TailFunction.apply(y, x, self.tail.weight(), self.skip.weight(), btot, self.scale, self.image_mean)
         return out, speed_accu
 
+    def _param_lists(self, idx):
+        """the per-block Parameter objects of blocks `idx`, gathered once (walking ModuleDict / Sequential containers for
+        ~20 tensors x 16 blocks costs more host time per step than the kernels they feed)"""
+        cache = self.__dict__.setdefault("_plist_cache", {})
+        if idx not in cache:
+            blocks = [self.body[i] for i in idx]
+            ks = ("3", "5", "7")
+            cache.clear()
+            cache[idx] = dict(
+                wn={(k, j): ([m.body[k][0].body[j].weight_v for m in blocks], [m.body[k][0].body[j].weight_g for m in blocks])
+                    for k in ks for j in (0, 2)},
+                bdw=[m.body[k][0].body[0].bias for m in blocks for k in ks],
+                bpw=[m.body[k][0].body[2].bias for m in blocks for k in ks],
+                split=[m.split.weight for m in blocks], alpha=[m.alpha for m in blocks],
+                vshape={(k, j): blocks[0].body[k][0].body[j].weight_v.shape for k in ks for j in (0, 2)} if blocks else {})
+        return cache[idx]
+
     def _body(self, y, mg):
         """All MyAggregationLayer blocks (reference wdsr_b.py:111-117 with :517-546 per block) through ONE autograd node:
         parameters are stacked over blocks so that weight-norm, masks, gates, softmax and the latency terms are a few
         batched ops, not a few dozen per block.  Returns (y NHWC, speed_accu (1,))."""
-        blocks = list(self.body)
+        nball = len(self.body)
+        idx = tuple(range(nball))
         if not self.training:                       # eval: a skipped block only applies the (idempotent 0/1) global mask
-            blocks = [m for m in blocks if not m._skipped()]
-        speed_all = list(self.body)
+            idx = tuple(i for i in idx if not self.body[i]._skipped())
+        allp = self._param_lists(tuple(range(nball))) if len(idx) == nball else None
+        if allp is None:
+            allp = dict(split=[m.split.weight for m in self.body], alpha=[m.alpha for m in self.body])
         dev = y.device
         # latency head, reference speed_estimator.py:57-76 (raw alpha, rounding() with its default least_channel = 8)
         with torch.no_grad():
             c_mask = rounding(self.mask.weight.detach()).sum()
-            W = torch.stack([m.split.weight.detach().reshape(-1) for m in speed_all])              # (NB, F)
+            W = torch.stack(allp["split"]).detach().view(nball, -1)                                 # (NB, F)
             kth = torch.topk(W, 8, dim=1).values[:, -1:]
             hard = (W >= 0.5).float()
             c_split = torch.where(hard.sum(1, keepdim=True) >= 8, hard, (W >= kth).float()).sum(1)
-            A = torch.stack([m.alpha.detach() for m in speed_all])                                  # (NB, 3)
+            A = torch.stack(allp["alpha"]).detach()                                                 # (NB, 3)
             speed_curr = ((c_split + 0.2 * c_mask).view(-1, 1) * _const(dev, (9.0, 25.0, 49.0)).view(1, 3) * A / 40).sum(1)
         if self.training:
-            gates = _GateFunction.apply(torch.cat([m.alpha1 for m in speed_all]), torch.cat([m.alpha2 for m in speed_all]))
-            for i, m in enumerate(speed_all):                                                       # reference :521-523
-                m.beta1.data, m.beta2.data = gates.detach()[i, 0:1], gates.detach()[i, 1:2]
+            gates = _GateFunction.apply(torch.cat([m.alpha1 for m in self.body]), torch.cat([m.alpha2 for m in self.body]))
+            gd = gates.detach()
+            for i, m in enumerate(self.body):                                                       # reference :521-523
+                m.beta1.data, m.beta2.data = gd[i, 0:1], gd[i, 1:2]
             speed_accu = (gates[:, 1] * speed_curr).sum().reshape(1)
         else:
             gates = None
-            speed_accu = (torch.cat([m.beta2 for m in speed_all]) * speed_curr).sum().reshape(1)
-        if not blocks:
+            speed_accu = (torch.cat([m.beta2 for m in self.body]) * speed_curr).sum().reshape(1)
+        if not idx:
             return y, speed_accu
-        idx = [i for i, m in enumerate(speed_all) if m in blocks] if len(blocks) != len(speed_all) else None
+        pl = self._param_lists(idx)
+        nbk = len(idx)
 
         def wn(k, j):                                # weight-normalised conv j (0 depthwise, 2 pointwise) of branch k
-            convs = [m.body[k][0].body[j] for m in blocks]
-            v = torch.cat([c.weight_v for c in convs])
-            gsc = torch.cat([c.weight_g for c in convs])
-            return torch._weight_norm(v, gsc, 0).view(len(blocks), *convs[0].weight_v.shape)
-        nbk = len(blocks)
+            vs, gs = pl["wn"][(k, j)]
+            return torch._weight_norm(torch.cat(vs), torch.cat(gs), 0).view(nbk, *pl["vshape"][(k, j)])
         WDW = [wn(k, 0) for k in ("3", "5", "7")]
         WPW = torch.stack([wn(k, 2) for k in ("3", "5", "7")], dim=1)                                # (nb, 3, F, F, 1, 1)
-        BDW = torch.stack([m.body[k][0].body[0].bias for m in blocks for k in ("3", "5", "7")]).view(nbk, 3, -1)
-        BPW = torch.stack([m.body[k][0].body[2].bias for m in blocks for k in ("3", "5", "7")]).view(nbk, 3, -1)
-        SW = torch.stack([m.split.weight.reshape(-1) for m in blocks])                              # (nb, F)
+        BDW = torch.stack(pl["bdw"]).view(nbk, 3, -1)
+        BPW = torch.stack(pl["bpw"]).view(nbk, 3, -1)
+        SW = torch.stack(pl["split"]).view(nbk, -1)                                                 # (nb, F)
         SWd = SW.detach()
         MS = SW - (SWd - (SWd >= 0.5).float())                   # BinaryConv2d(least_channel=0): value 0/1, gradient 1
-        P = F.softmax(torch.stack([m.alpha for m in blocks]), dim=1)
+        P = F.softmax(torch.stack(pl["alpha"]), dim=1)
         if self.training:
-            BETA = gates if idx is None else gates[idx]
+            BETA = gates
         else:
             BETA = _const(dev, (0.0, 1.0)).view(1, 2).expand(nbk, 2)
         y = _NasBodyFunction.apply(y, WDW[0], WDW[1], WDW[2], BDW, WPW, BPW, mg, MS, P, BETA)
