@@ -11,7 +11,7 @@ def test_library_exports_every_declared_symbol():
     lib = build.build()
     h = ctypes.CDLL(lib)
     header = open(os.path.join(ROOT, "include", "sr_hotpath.h")).read()
-    declared = set(re.findall(r"\bint\s+(sr_\w+)\s*\(", header))
+    declared = set(re.findall(r"\b(?:int|void|sr_graph_cache_t\*)\s+(sr_\w+)\s*\(", header))
     assert declared, "no declarations parsed"
     for name in declared:
         assert hasattr(h, name), f"{name} declared in sr_hotpath.h but not exported"
