@@ -75,10 +75,6 @@ int sr_wdsr_block2_fwd_repeat(void* x, void* ya, void* yb, const void* wblob_a, 
                               const float* cinit_a, const float* cinit_b, int N, int H, int W, int F, int dtype,
                               int reps, sr_stream_t stream);
 
-/* Diagnostic: one forward launch (bf16) that also records, per workgroup, 6 s_memrealtime stamps (100 MHz):
- * start, x/weights staged, after barrier, phase A done, after barrier, end -> stamps[wg][8]. */
-int sr_wdsr_block_fwd_stamps(const void* x, void* y, const void* wblob, const float* cinit, int N, int H, int W,
-                             int F, int dtype, unsigned long long* stamps, sr_stream_t stream);
 
 /* Fused residual block backward w.r.t. its input.  Replaces autograd's backward of Block.forward
  * (models/basic_wdsr_b.py:142-144): dx = dy + W1^T[1(h>0) * W2^T conv3x3^T(dy)], h recomputed from x.
@@ -97,11 +93,6 @@ int sr_wdsr_block_wgrad(const void* x, const void* dy, const void* wblob, const 
                         int N, int H, int W, int F, int dtype,
                         long x_ls, long dy_ls, long w_ls, long c_ls, sr_stream_t stream);
 int sr_wdsr_block_slab_sizes(int F, int* slab_a, int* slab_b);
-/* Diagnostic (bf16, F=24): same as sr_wdsr_block_wgrad plus s_memrealtime stamps, stamps[2][layers*wgs][128]. */
-int sr_wdsr_block_wgrad_stamps(const void* x, const void* dy, const void* wblob, const float* cinit,
-                               float* partial_a, float* partial_b, int layers, int wgs_per_layer, int N, int H, int W,
-                               long x_ls, long dy_ls, long w_ls, long c_ls, unsigned long long* stamps,
-                               sr_stream_t stream);
 
 /* Head conv forward.  Replaces `x - image_mean` + self.head(x), models/basic_wdsr_b.py:86-87:
  * x NCHW fp32 [N,3,H,W] in [0,1] -> y NHWC [N,H,W,F].  wblob: packing.ends_tables()["head"]. */
@@ -244,8 +235,9 @@ int sr_probe_launch_floor(void* out, int gx, int gy, int threads, int lds_bytes,
 /* The same chain captured in a hipGraph and replayed `iters` times (synchronous; result in *us_per_launch). */
 int sr_probe_launch_floor_graph(void* out, int gx, int gy, int threads, int lds_bytes, int reps, int iters,
                                 float* us_per_launch, float* host_us_per_graph /* may be NULL */);
-/* Debug: instrumented kernels (currently sr_tail_wgrad) write s_memrealtime stamps to buf[workgroup][32]
- * (u64) while the pointer is set; NULL switches it off.  Synchronous. */
+/* Debug: in the diagnostic build (libsr_hotpath_dbg.so, `python -m mobilesuperresolution_amd.build --debug`) the
+ * instrumented kernels write s_memrealtime stamps to buf[workgroup][16 waves][16] (NULL = off).  The product
+ * library contains no stamp code and returns -1. */
 int sr_debug_set_stamps(void* buf);
 
 #ifdef __cplusplus

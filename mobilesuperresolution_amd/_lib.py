@@ -9,7 +9,8 @@ from ctypes import c_int, c_size_t, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsr_hotpath.so")
+# SR_HOTPATH_DEBUG_LIB=1 (tools/ only): the diagnostic build with in-kernel time stamps (build.py --debug)
+LIB_PATH = os.path.join(_HERE, "libsr_hotpath_dbg.so" if os.environ.get("SR_HOTPATH_DEBUG_LIB") == "1" else "libsr_hotpath.so")
 ABI_VERSION = 3
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
 
@@ -29,11 +30,9 @@ SIGNATURES = {
     "sr_c3_trunk_bwd": ([_P] * 9 + [_I] * 7 + [_P], _I),
     "sr_tail_bwd": ([_P, _P, _P, _F, _P, _P, _P] + [_I] * 7 + [_P], _I),
     "sr_nas_dw_wgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
-    "sr_wdsr_block_fwd_stamps": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P], _I),
     "sr_wdsr_block_fwd_repeat": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block_bwd_data": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block_wgrad": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P], _I),
-    "sr_wdsr_block_wgrad_stamps": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P, _P], _I),
     "sr_wdsr_block_slab_sizes": ([_I, _P, _P], _I),
     "sr_head_fwd": ([_P, _P, _P, _F, _I, _I, _I, _I, _I, _P], _I),
     "sr_tail_fwd": ([_P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P], _I),

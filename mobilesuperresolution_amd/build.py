@@ -13,6 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsr_hotpath.so")
+LIB_DBG = os.path.join(HERE, "libsr_hotpath_dbg.so")     # diagnostic build (in-kernel stamps), tools/ only
 SOURCES = ["sr_abi.hip"]
 ARCH = "gfx950"
 
@@ -25,22 +26,25 @@ def _deps():
     return out
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def needs_build(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(d) > t for d in _deps())
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, debug: bool = False) -> str:
+    """debug=True builds libsr_hotpath_dbg.so with -DSR_DEBUG_STAMPS (never loaded by the product path)."""
+    LIB = LIB_DBG if debug else globals()["LIB"]
+    if not force and not needs_build(LIB):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-Rpass-analysis=kernel-resource-usage", "-I", os.path.join(HERE, "..", "include")]
-    cmd += os.environ.get("SR_EXTRA_HIPCC_FLAGS", "").split()       # experiments only (e.g. -DSR_EXP_...)
+    if debug:
+        cmd += ["-DSR_DEBUG_STAMPS"]
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
@@ -49,11 +53,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if res.returncode != 0:
         sys.stderr.write(res.stderr)
         raise RuntimeError("hipcc failed")
-    with open(os.path.join(HERE, "kernel_resources.txt"), "w") as f:
+    with open(os.path.join(HERE, "kernel_resources_dbg.txt" if debug else "kernel_resources.txt"), "w") as f:
         for k in report:
             f.write("{name} vgpr={vgpr} agpr={agpr} spill={spill} scratch={scratch} lds={lds} occ={occ}\n".format(**k))
     bad = [k for k in report if k["spill"] or k["scratch"]]
-    if bad:
+    if bad and debug:
+        sys.stderr.write("diagnostic build: spills in " + ", ".join(k["name"] for k in bad) + " (timing only)\n")
+    elif bad:
         # ROCm 7.2 hipcc miscompiles a partially spilled fragment (see csrc/sr_common.h): never ship a spill
         raise RuntimeError("register spills in: " + ", ".join(f"{k['name']} (spill {k['spill']})" for k in bad))
     os.replace(LIB + ".tmp", LIB)
@@ -82,4 +88,4 @@ def parse_resource_usage(text: str):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, debug="--debug" in sys.argv))

@@ -15,12 +15,12 @@ namespace {
 
 template <typename T, int F, int E, int L>
 int launch_block_fwd(const void* x, void* y, const void* wblob, const float* cinit, int N, int H, int W,
-                     hipStream_t st, unsigned long long* stamps = nullptr, void* tsave = nullptr) {
+                     hipStream_t st, void* tsave = nullptr) {
   typedef BlockCfg<F, E, L> C;
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
   dim3 grid(tiles_x * tiles_y, N), block(64 * C::NPT_H);
   hipLaunchKernelGGL((wdsr_block_fwd_kernel<T, F, E, L>), grid, block, 0, st, (const T*)x, (T*)y, (const T*)wblob,
-                     cinit, H, W, tiles_x, stamps, (T*)tsave);
+                     cinit, H, W, tiles_x, (T*)tsave);
   SR_HIP_CHECK_LAUNCH();
   return 0;
 }
@@ -40,16 +40,16 @@ int launch_block_bwd_data(const void* x, const void* dy, void* dx, const void* w
 template <typename T, int F, int E, int L>
 int launch_block_wgrad(const void* x, const void* dy, const void* wblob, const float* cinit, float* pa, float* pb,
                        int layers, int wgs, int N, int H, int W, long x_ls, long dy_ls, long w_ls, long c_ls,
-                       hipStream_t st, unsigned long long* stamps = nullptr) {
+                       hipStream_t st) {
   typedef BlockCfg<F, E, L> C;
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
   dim3 grid(wgs, layers);
   hipLaunchKernelGGL((wdsr_block_wgrad_kernel<T, F, E, L, 0>), grid, dim3(64 * WgradCfg<F, E, L, 0>::NWAVES), 0, st,
                      (const T*)x, (const T*)dy, (const T*)wblob, cinit, pa, N, H, W, tiles_x, tiles_x * tiles_y, x_ls,
-                     dy_ls, w_ls, c_ls, stamps);
+                     dy_ls, w_ls, c_ls);
   hipLaunchKernelGGL((wdsr_block_wgrad_kernel<T, F, E, L, 1>), grid, dim3(64 * WgradCfg<F, E, L, 1>::NWAVES), 0, st,
                      (const T*)x, (const T*)dy, (const T*)wblob, cinit, pb, N, H, W, tiles_x, tiles_x * tiles_y, x_ls,
-                     dy_ls, w_ls, c_ls, stamps ? stamps + (size_t)layers * wgs * 128 : nullptr);
+                     dy_ls, w_ls, c_ls);
   SR_HIP_CHECK_LAUNCH();
   return 0;
 }
@@ -68,15 +68,6 @@ extern "C" int sr_wdsr_block2_fwd(const void* x, void* ya, void* yb, const void*
                      (__bf16*)yb, (const __bf16*)wa, (const __bf16*)wb, cia, cib, (__bf16*)tsa, (__bf16*)tsb, H, W, tiles_x);
   SR_HIP_CHECK_LAUNCH();
   return 0;
-}
-
-extern "C" int sr_wdsr_block_fwd_stamps(const void* x, void* y, const void* wblob, const float* cinit, int N, int H,
-                                        int W, int F, int dtype, unsigned long long* stamps, sr_stream_t stream) {
-  if (F == 24 && dtype == SR_DTYPE_BF16)
-    return launch_block_fwd<__bf16, 24, 144, 20>(x, y, wblob, cinit, N, H, W, (hipStream_t)stream, stamps);
-  if (F == 32 && dtype == SR_DTYPE_BF16)
-    return launch_block_fwd<__bf16, 32, 192, 26>(x, y, wblob, cinit, N, H, W, (hipStream_t)stream, stamps);
-  return -1;
 }
 
 extern "C" int sr_wdsr_block_fwd_repeat(void* x, void* y, const void* wblob, const float* cinit, int N, int H, int W,
@@ -176,14 +167,6 @@ extern "C" int sr_wdsr_block_wgrad_saved(const void* x, const void* dy, const vo
   if (F == 24) return launch_wgrad_saved<24, 144, 20>(x, dy, tsave, dtsave, wblob, cinit, pa, pb, layers, wgs, N, H, W, x_ls, dy_ls, side_ls, w_ls, c_ls, st);
   if (F == 32) return launch_wgrad_saved<32, 192, 26>(x, dy, tsave, dtsave, wblob, cinit, pa, pb, layers, wgs, N, H, W, x_ls, dy_ls, side_ls, w_ls, c_ls, st);
   return -1;
-}
-
-extern "C" int sr_wdsr_block_wgrad_stamps(const void* x, const void* dy, const void* wblob, const float* cinit,
-                                          float* pa, float* pb, int layers, int wgs, int N, int H, int W, long x_ls,
-                                          long dy_ls, long w_ls, long c_ls, unsigned long long* stamps,
-                                          sr_stream_t stream) {
-  return launch_block_wgrad<__bf16, 24, 144, 20>(x, dy, wblob, cinit, pa, pb, layers, wgs, N, H, W, x_ls, dy_ls, w_ls,
-                                                 c_ls, (hipStream_t)stream, stamps);
 }
 
 extern "C" int sr_wdsr_block_slab_sizes(int F, int* slab_a, int* slab_b) {
@@ -623,10 +606,10 @@ extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int flags, sr_stream_
     if (save_acts && saved) {                     // single-block kernel that also keeps t (bf16)
       rc = n->F == 24 ? launch_block_fwd<__bf16, 24, 144, 20>(cur, nxt, (char*)n->blob_body + i * blob,
                                                               n->cinit_body + (size_t)i * n->n_idx_cinit, n->N, n->H, n->W,
-                                                              st, nullptr, (char*)n->tsave + (size_t)i * side)
+                                                              st, (char*)n->tsave + (size_t)i * side)
                       : launch_block_fwd<__bf16, 32, 192, 26>(cur, nxt, (char*)n->blob_body + i * blob,
                                                               n->cinit_body + (size_t)i * n->n_idx_cinit, n->N, n->H, n->W,
-                                                              st, nullptr, (char*)n->tsave + (size_t)i * side);
+                                                              st, (char*)n->tsave + (size_t)i * side);
       if (rc) return rc;
     } else if ((rc = sr_wdsr_block_fwd(cur, nxt, (char*)n->blob_body + i * blob,
                                        n->cinit_body + (size_t)i * n->n_idx_cinit, n->N, n->H, n->W, n->F, n->dtype, stream)))
@@ -848,8 +831,14 @@ extern "C" int sr_probe_launch_floor_graph(void* out, int gx, int gy, int thread
   return rc;
 }
 
-// debug: route in-kernel time stamps of the instrumented kernels to `buf` ([workgroup][32] u64; NULL = off)
+// debug: route the in-kernel time stamps of the diagnostic build to `buf` ([workgroup][16 waves][16] u64; NULL = off).
+// The product library carries no stamp code: there the call reports "unsupported".
 extern "C" int sr_debug_set_stamps(void* buf) {
+#ifdef SR_DEBUG_STAMPS
   unsigned long long* p = (unsigned long long*)buf;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_sr_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -3;
+#else
+  (void)buf;
+  return -1;
+#endif
 }

@@ -26,6 +26,19 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define SR_DEV __device__ __forceinline__
 
+// In-kernel time stamps exist only in the diagnostic build (-DSR_DEBUG_STAMPS -> libsr_hotpath_dbg.so, see
+// build.py); in the product library the macros are empty and no kernel carries a stamp pointer or a stamp load.
+// Layout: buf[workgroup][16 waves][16 stamps] of s_memrealtime (100 MHz), written by lane 0 of every wave.
+#ifdef SR_DEBUG_STAMPS
+__device__ unsigned long long* g_sr_stamps = nullptr;
+#define SR_STAMP_DECL int stamp_i_ = 0
+#define SR_STAMP() do { unsigned long long* sp_ = g_sr_stamps; if (sp_ && (threadIdx.x & 63) == 0 && stamp_i_ < 16 && (threadIdx.x >> 6) < 16) \
+    sp_[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (threadIdx.x >> 6)) * 16 + stamp_i_] = __builtin_amdgcn_s_memrealtime(); ++stamp_i_; } while (0)
+#else
+#define SR_STAMP_DECL do {} while (0)
+#define SR_STAMP() do {} while (0)
+#endif
+
 template <typename T> struct FragOf;
 template <> struct FragOf<__bf16> { typedef bf16x8 type; typedef bf16x4 half_type; };
 template <> struct FragOf<float>  { typedef f32x8 type;  typedef f32x4 half_type; };
@@ -41,11 +54,32 @@ template <> SR_DEV f32x16 mma16<float>(f32x8 a, f32x8 b, f32x16 c) {
   return c;
 }
 
+// two fp32 -> one packed pair.  bf16: ONE v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN kept); element-wise
+// casts make hipcc emit one conversion per value plus a v_perm_b32 per pair (3 VALU ops instead of 1).
+template <typename T> SR_DEV void cvt_pair(T& lo, T& hi, float a, float b) {
+  if constexpr (sizeof(T) == 2) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+    const f32x2_ v = {a, b};
+    const bf16x2_ p = __builtin_convertvector(v, bf16x2_);
+    lo = p[0];
+    hi = p[1];
+  } else {
+    lo = a;
+    hi = b;
+  }
+}
+
 // accumulator regs 8s..8s+7 -> fragment (chained k order)
 template <typename T, int S> SR_DEV typename FragOf<T>::type acc_to_frag(const f32x16& acc) {
   typename FragOf<T>::type f;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) f[j] = (T)acc[8 * S + j];
+  for (int j = 0; j < 8; j += 2) {
+    T lo, hi;
+    cvt_pair<T>(lo, hi, acc[8 * S + j], acc[8 * S + j + 1]);
+    f[j] = lo;
+    f[j + 1] = hi;
+  }
   return f;
 }
 
@@ -72,7 +106,12 @@ template <typename T, int S> SR_DEV typename FragOf<T>::type acc_to_frag_relu(co
 template <typename T> SR_DEV typename FragOf<T>::half_type acc_group(const f32x16& acc, int g) {
   typename FragOf<T>::half_type v;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = (T)acc[4 * g + j];
+  for (int j = 0; j < 4; j += 2) {
+    T lo, hi;
+    cvt_pair<T>(lo, hi, acc[4 * g + j], acc[4 * g + j + 1]);
+    v[j] = lo;
+    v[j + 1] = hi;
+  }
   return v;
 }
 
@@ -126,9 +165,6 @@ template <typename T> struct WSrc<T, true> {
   const T* p;
   SR_DEV void tile() {}
   SR_DEV typename FragOf<T>::type get(int idx, int lane) const {
-#ifdef SR_EXP_NO_WEIGHT_READS   // timing experiment only (wrong results): how much of a phase is LDS weight traffic
-    idx = 0;
-#endif
     return *reinterpret_cast<const typename FragOf<T>::type*>(p + (idx * 64 + lane) * 8);
   }
 };
@@ -139,11 +175,20 @@ template <typename T> struct WSrc<T, false> {
   SR_DEV typename FragOf<T>::type get(int idx, int lane) const { return load_wfrag<T>(p, idx, lane); }
 };
 
-// copy `nfrag` packed fragments (512 elements each) global -> LDS with all threads of the workgroup
+// copy `nfrag` packed fragments (512 elements each) global -> LDS by LDS-DMA (global_load_lds_dwordx4: one
+// wave-instruction moves 64 lanes x 16 B to M0 + lane * 16, exactly the lane-major fragment layout).  No
+// registers, no wait: every piece is in flight at once; the data is readable after the issuing wave's
+// s_waitcnt vmcnt and a workgroup barrier (__syncthreads() emits both).  A register-staged copy loop compiles
+// to load / vmcnt(0) / ds_write per iteration, i.e. one L2 round trip per 16 bytes per thread.
 template <typename T, int NTHREADS> SR_DEV void stage_weights(T* dst, const T* __restrict__ src, int nfrag, int tid) {
-  typedef typename FragOf<T>::type FragT;
-  for (int i = tid; i < nfrag * 64; i += NTHREADS)
-    *reinterpret_cast<FragT*>(dst + i * 8) = *reinterpret_cast<const FragT*>(src + (size_t)i * 8);
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  constexpr int NW = NTHREADS / 64, PIECES = (int)sizeof(T) * 512 / 1024;   // 1 KiB pieces per fragment
+  const int lane = tid & 63, wave = tid >> 6;
+  const char* s = reinterpret_cast<const char*>(src);
+  char* d = reinterpret_cast<char*>(dst);
+  for (int p = wave; p < nfrag * PIECES; p += NW)
+    __builtin_amdgcn_global_load_lds((gptr_t)(s + (size_t)p * 1024 + lane * 16), (lptr_t)(d + p * 1024), 16, 0, 0);
 }
 
 // 8 consecutive elements from an LDS image (16-byte aligned element offset)

@@ -62,6 +62,43 @@ SR_DEV void stage_x_halo(T* Xs, const T* __restrict__ xin, int H, int W, int ty0
   }
 }
 
+// t^T[l, px] = W2 relu(W1 x + b1) + b2 for one 32-pixel tile whose x fragments are in `xb` (rows l in regs,
+// pixels on lanes).  PIPE: the conv1 products of e-tile et+1 are issued BEFORE the convert/ReLU of e-tile et,
+// so a wave always has independent MFMAs to issue while its VALU turns the previous accumulator into the next
+// B operand (the serial form leaves the matrix pipe idle for the MFMA->VALU latency plus ~16 VALU ops per
+// e-tile and per wave).  Same products in the same order either way: results are bit-identical.
+template <typename T, typename C, typename WS, bool PIPE>
+SR_DEV f32x16 t_from_xb(const typename FragOf<T>::type (&xb)[C::KS1], const WS& wsrc, const float* __restrict__ cinit,
+                        int lane) {
+  const int hh = lane >> 5;
+  f32x16 tacc = load_cinit(cinit, hh);
+  auto conv1 = [&](int et) {
+    f32x16 hacc = C::FOLD_B1 ? zero16() : load_cinit(cinit + 32 + et * 32, hh);
+#pragma unroll
+    for (int s = 0; s < C::KS1; ++s) hacc = mma16<T>(wsrc.get(C::W1_OFF + et * C::KS1 + s, lane), xb[s], hacc);
+    return hacc;
+  };
+  if constexpr (PIPE) {
+    f32x16 hacc = conv1(0);
+#pragma unroll
+    for (int et = 0; et < C::NET; ++et) {
+      f32x16 hnext = hacc;
+      if (et + 1 < C::NET) hnext = conv1(et + 1);
+      if (2 * et < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * et, lane), acc_to_frag_relu<T, 0>(hacc), tacc);
+      if (2 * et + 1 < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * et + 1, lane), acc_to_frag_relu<T, 1>(hacc), tacc);
+      hacc = hnext;
+    }
+  } else {
+#pragma unroll 1
+    for (int et = 0; et < C::NET; ++et) {
+      const f32x16 hacc = conv1(et);
+      if (2 * et < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * et, lane), acc_to_frag_relu<T, 0>(hacc), tacc);
+      if (2 * et + 1 < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * et + 1, lane), acc_to_frag_relu<T, 1>(hacc), tacc);
+    }
+  }
+  return tacc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward:  y = conv3x3(W3, conv1x1(W2, relu(conv1x1(W1, x) + b1)) + b2) + b3 + x
 // grid = (tiles_y * tiles_x, N); one wave per 32-pixel tile of the halo'd region (NPT_H waves).
@@ -69,15 +106,13 @@ SR_DEV void stage_x_halo(T* Xs, const T* __restrict__ xin, int H, int W, int ty0
 template <typename T, int F, int E, int L>
 __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block_fwd_kernel(
     const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ wblob,
-    const float* __restrict__ cinit, int H, int W, int tiles_x, unsigned long long* __restrict__ stamps,
-    T* __restrict__ tsave) {
+    const float* __restrict__ cinit, int H, int W, int tiles_x, T* __restrict__ tsave) {
   typedef BlockCfg<F, E, L> C;
   typedef typename FragOf<T>::type FragT;
   typedef typename FragOf<T>::half_type HalfT;
   constexpr int NTHREADS = 64 * C::NPT_H;
-  // diagnostic phase stamps (sr_wdsr_block_fwd_stamps only; nullptr on the product path)
-#define SR_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-  SR_STAMP(0);
+  SR_STAMP_DECL;
+  SR_STAMP();
   constexpr bool WLDS = (sizeof(T) == 2);
   constexpr int TS0 = C::NPXH_PAD * C::KX, W0 = C::NPXH_PAD * (C::KX + C::LP);
   // one LDS array (x tile, t tile, packed weights) so that every fragment address is an offset into it
@@ -98,9 +133,9 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block_fw
     wsrc.p0 = wblob;
   }
   stage_x_halo<T, C, NTHREADS>(Xs, xin, H, W, ty0, tx0, tid);
-  SR_STAMP(1);
+  SR_STAMP();
   __syncthreads();
-  SR_STAMP(2);
+  SR_STAMP();
 
   // ---- phase A: t = W2 relu(W1 x + b1) + b2 on every halo'd pixel (zero outside the image) ----
   {
@@ -109,15 +144,7 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block_fw
     FragT xb[C::KS1];
 #pragma unroll
     for (int s = 0; s < C::KS1; ++s) xb[s] = lds_chunk<T>(Xs, hp * C::KX + (2 * s + hh) * 8);
-    f32x16 tacc = load_cinit(cinit, hh);
-#pragma unroll
-    for (int et = 0; et < C::NET; ++et) {
-      f32x16 hacc = C::FOLD_B1 ? zero16() : load_cinit(cinit + 32 + et * 32, hh);
-#pragma unroll
-      for (int s = 0; s < C::KS1; ++s) hacc = mma16<T>(wsrc.get(C::W1_OFF + et * C::KS1 + s, lane), xb[s], hacc);
-      if (2 * et < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * et, lane), acc_to_frag_relu<T, 0>(hacc), tacc);
-      if (2 * et + 1 < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * et + 1, lane), acc_to_frag_relu<T, 1>(hacc), tacc);
-    }
+    const f32x16 tacc = t_from_xb<T, C, WSrc<T, WLDS>, (sizeof(T) == 2)>(xb, wsrc, cinit, lane);
     bool valid = false;
     if (hp < C::NPXH) {
       const int hy = hp / C::HW, hx = hp - hy * C::HW;
@@ -140,9 +167,9 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block_fw
       }
     }
   }
-  SR_STAMP(3);
+  SR_STAMP();
   __syncthreads();
-  SR_STAMP(4);
+  SR_STAMP();
 
   // ---- phase B: y = sum_taps W3_tap t(shifted) + b3 (ones channel) + x (identity chunks) ----
   if (wave < C::NPT_O) {
@@ -172,8 +199,7 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block_fw
       for (int g = 0; g < C::FC; ++g) stream_store(reinterpret_cast<HalfT*>(yo + g * 8 + hh * 4), acc_group<T>(oacc, g));
     }
   }
-  SR_STAMP(5);
-#undef SR_STAMP
+  SR_STAMP();
 }
 
 // =============================================================================================
@@ -436,17 +462,7 @@ SR_DEV void scratch_store(T* scr, const f32x16& acc, bool valid, int r, int hh) 
 template <typename T, typename C, typename WS, int UNROLL>
 SR_DEV f32x16 t_tile(const typename FragOf<T>::type (&xb)[C::KS1], const WS& wsrc, const float* __restrict__ cinit,
                      int lane) {
-  const int hh = lane >> 5;
-  f32x16 tacc = load_cinit(cinit, hh);
-#pragma unroll UNROLL
-  for (int e2 = 0; e2 < C::NET; ++e2) {
-    f32x16 hacc = C::FOLD_B1 ? zero16() : load_cinit(cinit + 32 + e2 * 32, hh);
-#pragma unroll
-    for (int s = 0; s < C::KS1; ++s) hacc = mma16<T>(wsrc.get(C::W1_OFF + e2 * C::KS1 + s, lane), xb[s], hacc);
-    if (2 * e2 < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * e2, lane), acc_to_frag_relu<T, 0>(hacc), tacc);
-    if (2 * e2 + 1 < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * e2 + 1, lane), acc_to_frag_relu<T, 1>(hacc), tacc);
-  }
-  return tacc;
+  return t_from_xb<T, C, WS, (UNROLL > 1)>(xb, wsrc, cinit, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -471,12 +487,11 @@ template <typename T, int F, int E, int L, int ROLE>
 __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_block_wgrad_kernel(
     const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ wblob,
     const float* __restrict__ cinit, float* __restrict__ partial, int N, int H, int W, int tiles_x,
-    int tiles_per_img, long x_ls, long dy_ls, long w_ls, long c_ls, unsigned long long* __restrict__ stamps) {
+    int tiles_per_img, long x_ls, long dy_ls, long w_ls, long c_ls) {
   typedef BlockCfg<F, E, L> C;
   typedef BwdCfg<C> B;
   typedef WgradCfg<F, E, L, ROLE> G;
-  int stamp_i = 0;
-#define SR_STAMP() do { if (stamps && threadIdx.x == 0 && stamp_i < 120) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 128 + stamp_i++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  SR_STAMP_DECL;
   SR_STAMP();
   typedef typename FragOf<T>::type FragT;
   constexpr int NTHREADS = 64 * G::NWAVES;
@@ -693,7 +708,6 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
     SR_STAMP();
   }
   SR_STAMP();
-#undef SR_STAMP
 }
 
 // =============================================================================================
@@ -723,16 +737,7 @@ SR_DEV f32x16 t_from_x(const T* Ximg, int xrow, const WS& wsrc, const float* __r
   FragT xb[C::KS1];
 #pragma unroll
   for (int s = 0; s < C::KS1; ++s) xb[s] = lds_chunk<T>(Ximg, xrow * C::KX + (2 * s + hh) * 8);
-  f32x16 tacc = load_cinit(cinit, hh);
-#pragma unroll
-  for (int et = 0; et < C::NET; ++et) {
-    f32x16 hacc = C::FOLD_B1 ? zero16() : load_cinit(cinit + 32 + et * 32, hh);
-#pragma unroll
-    for (int s = 0; s < C::KS1; ++s) hacc = mma16<T>(wsrc.get(C::W1_OFF + et * C::KS1 + s, lane), xb[s], hacc);
-    if (2 * et < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * et, lane), acc_to_frag_relu<T, 0>(hacc), tacc);
-    if (2 * et + 1 < C::KS2) tacc = mma16<T>(wsrc.get(C::W2_OFF + 2 * et + 1, lane), acc_to_frag_relu<T, 1>(hacc), tacc);
-  }
-  return tacc;
+  return t_from_xb<T, C, WS, true>(xb, wsrc, cinit, lane);
 }
 
 // 3x3 + bias + residual for one pixel per lane pair: taps at Timg[(trow + ty*tstride + tx)], residual from Ximg[xrow]
@@ -777,6 +782,8 @@ __global__ __launch_bounds__((64 * Pair<F, E, L>::NWAVES)) void wdsr_block2_fwd_
   const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
   const size_t img = (size_t)n * H * W * F;
   const size_t tile_g = (size_t)n * gridDim.x + tile;            // tile index of the saved t images
+  SR_STAMP_DECL;
+  SR_STAMP();
 
   // ---- stage: both weight sets, x on the 2-pixel-halo region (zero outside the image, ones channel) ----
   stage_weights<T, NTHREADS>(WL, wa, C::NFRAG_FWD, tid);
@@ -817,7 +824,9 @@ __global__ __launch_bounds__((64 * Pair<F, E, L>::NWAVES)) void wdsr_block2_fwd_
       *reinterpret_cast<FragT*>(XB + idx * 8) = z;
     }
   }
+  SR_STAMP();
   __syncthreads();
+  SR_STAMP();
 
   // ---- A1: t1 on the 16x28 region ----
   {
@@ -838,7 +847,9 @@ __global__ __launch_bounds__((64 * Pair<F, E, L>::NWAVES)) void wdsr_block2_fwd_
         stream_store(reinterpret_cast<HalfT*>(tsa + (tile_g * (C::TH * C::TW) + (hy - 2) * C::TW + hx - 2) * C::LP + g * 8 + hh * 4), v);
     }
   }
+  SR_STAMP();
   __syncthreads();
+  SR_STAMP();
 
   // ---- B1: y1 on the 14x26 region -> XB (and HBM for the core pixels) ----
   if (wave < C::NPT_H) {
@@ -858,7 +869,9 @@ __global__ __launch_bounds__((64 * Pair<F, E, L>::NWAVES)) void wdsr_block2_fwd_
       }
     }
   }
+  SR_STAMP();
   __syncthreads();
+  SR_STAMP();
 
   // ---- A2: t2 on the 14x26 region (over the t1 image) ----
   if (wave < C::NPT_H) {
@@ -884,7 +897,9 @@ __global__ __launch_bounds__((64 * Pair<F, E, L>::NWAVES)) void wdsr_block2_fwd_
         stream_store(reinterpret_cast<HalfT*>(tsb + (tile_g * (C::TH * C::TW) + (hy1 - 1) * C::TW + hx1 - 1) * C::LP + g * 8 + hh * 4), v);
     }
   }
+  SR_STAMP();
   __syncthreads();
+  SR_STAMP();
 
   // ---- B2: y2 on the core ----
   if (wave < C::NPT_O) {
@@ -898,6 +913,7 @@ __global__ __launch_bounds__((64 * Pair<F, E, L>::NWAVES)) void wdsr_block2_fwd_
       for (int g = 0; g < C::FC; ++g) stream_store(reinterpret_cast<HalfT*>(o + g * 8 + hh * 4), acc_group<T>(oacc, g));
     }
   }
+  SR_STAMP();
 }
 
 // =============================================================================================

@@ -346,9 +346,6 @@ __global__ __launch_bounds__(256) void sr_tail_bwd_data_kernel(const float* __re
 // tile the workgroup walks (no cross-wave reduction), pixels contracted through transposed LDS reads.
 // Slab per workgroup: [TAIL_TILES][16][64]; layout in packing.ends_grad_tables.
 // ---------------------------------------------------------------------------------------------
-// debug time stamps (tools/stamp_ends.py): [workgroup][32] s_memrealtime values when the pointer is set
-__device__ unsigned long long* g_sr_stamps = nullptr;
-#define SR_GSTAMP() do { unsigned long long* sp_ = g_sr_stamps; if (sp_ && threadIdx.x == 0 && stamp_i < 32) sp_[(size_t)blockIdx.x * 32 + stamp_i++] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 template <typename T, int F, int R>
 __global__ __launch_bounds__(896) void sr_tail_wgrad_kernel(const float* __restrict__ dout, const T* __restrict__ feat,
@@ -371,20 +368,20 @@ __global__ __launch_bounds__(896) void sr_tail_wgrad_kernel(const float* __restr
 #pragma unroll
   for (int i = 0; i < NT; ++i) acc[i] = zero16();
 
-  int stamp_i = 0;
-  SR_GSTAMP();
+  SR_STAMP_DECL;
+  SR_STAMP();
   for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
     const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
     const int ty0 = (tile / tiles_x) * E::TH, tx0 = (tile % tiles_x) * E::TW;
     __syncthreads();
-    SR_GSTAMP();
+    SR_STAMP();
     stage_dconv<T, E, 0, NTHREADS>(DC, dout + (size_t)n * 3 * H * R * W * R, H, W, ty0, tx0, tid);
-    SR_GSTAMP();
+    SR_STAMP();
     stage_halo<T, E, F, NTHREADS>(FT, feat + (size_t)n * H * W * F, H, W, ty0, tx0, tid);
     stage_img<T, E, 2, NTHREADS>(XI, ximg + (size_t)n * 3 * H * W, mean, H, W, ty0, tx0, tid);
-    SR_GSTAMP();
+    SR_STAMP();
     __syncthreads();
-    SR_GSTAMP();
+    SR_STAMP();
     constexpr int UNR = sizeof(T) == 2 ? 3 : 1;
 #pragma unroll UNR
     for (int ot = 0; ot < E::NPT_O; ++ot) {
@@ -402,7 +399,7 @@ __global__ __launch_bounds__(896) void sr_tail_wgrad_kernel(const float* __restr
       }
     }
   }
-  SR_GSTAMP();
+  SR_STAMP();
   // global tile index: taps (ty*3 + tx)*NT + ti ; skip rows 9*NT + ky*NT + ti
   float* out = partial + (size_t)blockIdx.x * E::TAIL_TILES * 1024;
   const int gbase = is_tap ? (ty * 3 + tx) * NT : (9 + ty) * NT;
@@ -410,7 +407,7 @@ __global__ __launch_bounds__(896) void sr_tail_wgrad_kernel(const float* __restr
   for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
     for (int i = 0; i < 16; ++i) out[((gbase + ti) * 16 + i) * 64 + lane] = acc[ti][i];
-  SR_GSTAMP();
+  SR_STAMP();
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,25 +1,50 @@
-"""Diagnostic: per-phase timeline of the fused block forward kernel from in-kernel stamps."""
+"""Diagnostic: per-phase, per-wave timeline of the block forward kernels from in-kernel stamps.
+Needs the diagnostic library: python -m mobilesuperresolution_amd.build --debug; run with SR_HOTPATH_DEBUG_LIB=1.
+    SR_HOTPATH_DEBUG_LIB=1 python tools/stamp_fwd.py [pair|single] [batch]"""
 import os, sys
+os.environ["SR_HOTPATH_DEBUG_LIB"] = "1"
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mobilesuperresolution_amd import _lib as L, hotpath as HP
-f, n = 24, 32
-src = torch.randn(1, HP.tables(f, torch.device("cuda", 0))["src_size"], device="cuda") * 0.1
+mode = sys.argv[1] if len(sys.argv) > 1 else "pair"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+f = 24
+dev = torch.device("cuda", 0)
+src = torch.randn(2, HP.tables(f, dev)["src_size"], device="cuda") * 0.1
 blob, cinit = HP.pack_blocks(src, f, torch.bfloat16)
 x = torch.randn(n, 48, 48, f, device="cuda").bfloat16()
-y = torch.empty_like(x)
+ya = torch.empty_like(x); yb = torch.empty_like(x)
 nwg = n * 8
-st = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
+st = torch.zeros(nwg * 16 * 16, dtype=torch.int64, device="cuda")
+lib = L.lib()
+def run():
+    if mode == "pair":
+        L.check(lib.sr_wdsr_block2_fwd(x.data_ptr(), ya.data_ptr(), yb.data_ptr(), blob[0].data_ptr(), blob[1].data_ptr(),
+                                       cinit[0].data_ptr(), cinit[1].data_ptr(), None, None, n, 48, 48, f, 1, L.stream_ptr()), "pair")
+    else:
+        L.check(lib.sr_wdsr_block_fwd(x.data_ptr(), ya.data_ptr(), blob[0].data_ptr(), cinit[0].data_ptr(), n, 48, 48, f, 1,
+                                      L.stream_ptr()), "single")
 for it in range(5):
-    HP.block_fwd(x, y, blob[0], cinit[0])
-    L.check(L.lib().sr_wdsr_block_fwd_stamps(x.data_ptr(), y.data_ptr(), blob[0].data_ptr(), cinit[0].data_ptr(),
-                                             n, 48, 48, f, 1, st.data_ptr(), L.stream_ptr()), "stamps")
+    run()
 torch.cuda.synchronize()
-s = st.cpu().numpy().reshape(nwg, 8)[:, :6].astype(np.float64) * 10.0      # ns (100 MHz)
-t0 = s[:, 0].min()
-print("workgroup start spread (ns): min %.0f max %.0f" % (0, s[:, 0].max() - t0))
-names = ["stage issue->stored", "barrier1", "phase A", "barrier2", "phase B + store"]
-for k in range(5):
-    d = s[:, k + 1] - s[:, k]
-    print("%-22s mean %7.0f ns  min %7.0f  max %7.0f" % (names[k], d.mean(), d.min(), d.max()))
-print("per-WG total mean %.0f ns; first start -> last end %.0f ns" % ((s[:, 5] - s[:, 0]).mean(), s[:, 5].max() - t0))
+L.check(lib.sr_debug_set_stamps(st.data_ptr()), "set")
+for it in range(3):
+    run()
+torch.cuda.synchronize()
+L.check(lib.sr_debug_set_stamps(None), "unset")
+s = st.cpu().numpy().reshape(nwg, 16, 16).astype(np.float64) * 10.0      # ns (100 MHz)
+nst = int((s[0, 0] > 0).sum())
+nw = int((s[0, :, 0] > 0).sum())
+t0 = s[:, :nw, 0].min()
+print(f"{mode} batch {n}: {nwg} workgroups, {nw} waves, {nst} stamps; first start -> last end {s[:, :nw, nst - 1].max() - t0:.0f} ns")
+print("workgroup start spread %.0f ns" % (s[:, 0, 0].max() - t0))
+names = (["stage issue", "wait+barrier", "A1", "barrier", "B1", "barrier", "A2", "barrier", "B2+store"] if mode == "pair"
+         else ["stage issue", "wait+barrier", "A", "barrier", "B+store"])
+for k in range(nst - 1):
+    d = s[:, :nw, k + 1] - s[:, :nw, k]
+    act = d[d < 1e6]
+    per_wave = np.median(d, axis=0)
+    print("%-14s median %6.0f  p10 %6.0f  p90 %6.0f   per-wave median: %s" % (names[k] if k < len(names) else k, np.median(act), np.percentile(act, 10),
+          np.percentile(act, 90), " ".join("%4.0f" % v for v in per_wave)))
+tot = s[:, :nw, nst - 1].max(axis=1) - s[:, :nw, 0].min(axis=1)
+print("per-WG total median %.0f ns" % np.median(tot))
