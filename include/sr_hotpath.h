@@ -42,7 +42,7 @@ int sr_wdsr_block_fwd(const void* x, void* y, const void* wblob, const float* ci
 
 /* Two consecutive residual blocks in one launch (bf16, F = 24 only; -1 otherwise): x -> ya (block A's
  * output, kept because backward needs every block input; NULL = do not store) -> yb.  Bit-identical to two sr_wdsr_block_fwd
- * calls; exists because a single block launch at batch 32 is bound by its fixed costs. */
+ * calls; exists because a single block launch at batch 32 is bound by its fixed costs.  (= sr_wdsr_fwd_rs with nblk = 2.) */
 int sr_wdsr_block2_fwd(const void* x, void* ya, void* yb, const void* wblob_a, const void* wblob_b,
                        const float* cinit_a, const float* cinit_b, void* tsave_a, void* tsave_b, int N, int H, int W,
                        int F, int dtype, sr_stream_t stream);
@@ -65,6 +65,18 @@ int sr_wdsr_block_wgrad_saved(const void* x, const void* dy, const void* tsave, 
                               const void* wblob, const float* cinit, float* partial_a, float* partial_b, int layers,
                               int wgs, int N, int H, int W, int F, int dtype, long x_ls, long dy_ls, long side_ls,
                               long w_ls, long c_ls, sr_stream_t stream);
+
+/* Forward of nblk = 1 or 2 consecutive residual blocks with register-resident weights (bf16, F = 24 only; -1
+ * otherwise): every wave keeps the weights of its current phase in registers, x / weights are staged by LDS-DMA
+ * (csrc/wdsr_fwd_rs.h).  Same
+ * arguments and bit-identical results as sr_wdsr_block_fwd (nblk = 1: x -> yb, the *_b / ya arguments unused)
+ * and sr_wdsr_block2_fwd (nblk = 2). */
+int sr_wdsr_fwd_rs(const void* x, void* ya, void* yb, const void* wblob_a, const void* wblob_b, const float* cinit_a,
+                   const float* cinit_b, void* tsave_a, void* tsave_b, int nblk, int N, int H, int W, int F, int dtype,
+                   sr_stream_t stream);
+int sr_wdsr_fwd_rs_repeat(void* x, void* ya, void* yb, const void* wblob_a, const void* wblob_b, const float* cinit_a,
+                          const float* cinit_b, int nblk, int N, int H, int W, int F, int dtype, int reps,
+                          sr_stream_t stream);
 
 /* Measurement aid for bench.py's roofline leg: `reps` back-to-back launches of the same forward kernel,
  * ping-ponging x <-> y, so that HIP events around the call measure the kernel and not the host. */

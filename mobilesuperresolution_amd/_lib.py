@@ -20,6 +20,8 @@ SIGNATURES = {
     "sr_abi_version": ([], _I),
     "sr_wdsr_block_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block2_fwd": ([_P] * 9 + [_I] * 5 + [_P], _I),
+    "sr_wdsr_fwd_rs": ([_P] * 9 + [_I] * 6 + [_P], _I),
+    "sr_wdsr_fwd_rs_repeat": ([_P] * 7 + [_I] * 7 + [_P], _I),
     "sr_wdsr_block_wgrad_saved": ([_P] * 8 + [_I] * 7 + [_L] * 5 + [_P], _I),
     "sr_wdsr_block2_bwd_data": ([_P] * 11 + [_I] * 5 + [_P], _I),
     "sr_wdsr_block2_fwd_repeat": ([_P] * 7 + [_I] * 6 + [_P], _I),

@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include "../../include/sr_hotpath.h"
 #include "wdsr_block.h"
+#include "wdsr_fwd_rs.h"
 #include "wdsr_ends.h"
 #include "wdsr_prep.h"
 #include "conv3x3.h"
@@ -56,17 +57,46 @@ int launch_block_wgrad(const void* x, const void* dy, const void* wblob, const f
 
 }  // namespace
 
+// forward with register-resident weights (csrc/wdsr_fwd_rs.h): nblk = 1 (x -> yb) or 2 (x -> ya -> yb)
+template <int F, int E, int L, int NBLK>
+static int launch_fwd_rs(const void* x, void* ya, void* yb, const void* wa, const void* wb, const float* cia, const float* cib,
+                         void* tsa, void* tsb, int N, int H, int W, hipStream_t st) {
+  typedef BlockCfg<F, E, L> C;
+  typedef __bf16 T;
+  const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
+  if (tsa && (NBLK == 1 || tsb))
+    hipLaunchKernelGGL((wdsr_fwd_rs_kernel<F, E, L, NBLK, true>), dim3(tiles_x * tiles_y, N), dim3(512), 0, st, (const T*)x, (T*)ya,
+                       (T*)yb, (const T*)wa, (const T*)wb, cia, cib, (T*)tsa, (T*)tsb, H, W, tiles_x);
+  else
+    hipLaunchKernelGGL((wdsr_fwd_rs_kernel<F, E, L, NBLK, false>), dim3(tiles_x * tiles_y, N), dim3(512), 0, st, (const T*)x, (T*)ya,
+                       (T*)yb, (const T*)wa, (const T*)wb, cia, cib, (T*)tsa, (T*)tsb, H, W, tiles_x);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int sr_wdsr_fwd_rs(const void* x, void* ya, void* yb, const void* wa, const void* wb, const float* cia,
+                              const float* cib, void* tsa, void* tsb, int nblk, int N, int H, int W, int F, int dtype,
+                              sr_stream_t stream) {
+  if (!x || !yb || !wa || !cia || N <= 0 || H <= 0 || W <= 0 || N > 65535 || (nblk == 2 && (!wb || !cib))) return -2;
+  if (dtype != SR_DTYPE_BF16) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  if (F == 24 && nblk == 2) return launch_fwd_rs<24, 144, 20, 2>(x, ya, yb, wa, wb, cia, cib, tsa, tsb, N, H, W, st);
+  if (F == 24 && nblk == 1) return launch_fwd_rs<24, 144, 20, 1>(x, nullptr, yb, wa, nullptr, cia, nullptr, tsa, nullptr, N, H, W, st);
+  return -1;
+}
 extern "C" int sr_wdsr_block2_fwd(const void* x, void* ya, void* yb, const void* wa, const void* wb, const float* cia,
                                   const float* cib, void* tsa, void* tsb, int N, int H, int W, int F, int dtype,
                                   sr_stream_t stream) {
-  if (!x || !yb || !wa || !wb || !cia || !cib || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
-  if (F != 24 || dtype != SR_DTYPE_BF16) return -1;
-  typedef BlockCfg<24, 144, 20> C;
-  const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
-  hipLaunchKernelGGL((wdsr_block2_fwd_kernel<__bf16, 24, 144, 20>), dim3(tiles_x * tiles_y, N),
-                     dim3(64 * Pair<24, 144, 20>::NWAVES), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)ya,
-                     (__bf16*)yb, (const __bf16*)wa, (const __bf16*)wb, cia, cib, (__bf16*)tsa, (__bf16*)tsb, H, W, tiles_x);
-  SR_HIP_CHECK_LAUNCH();
+  if (F != 24) return (!x || !yb || !wa || !wb || !cia || !cib || N <= 0 || H <= 0 || W <= 0 || N > 65535) ? -2 : -1;
+  return sr_wdsr_fwd_rs(x, ya, yb, wa, wb, cia, cib, tsa, tsb, 2, N, H, W, F, dtype, stream);
+}
+extern "C" int sr_wdsr_fwd_rs_repeat(void* x, void* ya, void* yb, const void* wa, const void* wb, const float* cia,
+                                     const float* cib, int nblk, int N, int H, int W, int F, int dtype, int reps,
+                                     sr_stream_t stream) {
+  for (int i = 0; i < reps; ++i) {
+    const int rc = (i & 1) ? sr_wdsr_fwd_rs(yb, ya, x, wa, wb, cia, cib, nullptr, nullptr, nblk, N, H, W, F, dtype, stream)
+                           : sr_wdsr_fwd_rs(x, ya, yb, wa, wb, cia, cib, nullptr, nullptr, nblk, N, H, W, F, dtype, stream);
+    if (rc) return rc;
+  }
   return 0;
 }
 
@@ -603,6 +633,14 @@ extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int flags, sr_stream_
       continue;
     }
     char* nxt = save_acts ? acts + (size_t)(i + 1) * act : (cur == acts ? acts + act : acts);
+    if (pairs) {                                  // odd block count at a launch-bound grid: same kernel family, one block
+      char* ts = (save_acts && saved) ? (char*)n->tsave + (size_t)i * side : nullptr;
+      if ((rc = sr_wdsr_fwd_rs(cur, nullptr, nxt, (char*)n->blob_body + i * blob, nullptr, n->cinit_body + (size_t)i * n->n_idx_cinit,
+                               nullptr, ts, nullptr, 1, n->N, n->H, n->W, n->F, n->dtype, stream)))
+        return rc;
+      cur = nxt;
+      continue;
+    }
     if (save_acts && saved) {                     // single-block kernel that also keeps t (bf16)
       rc = n->F == 24 ? launch_block_fwd<__bf16, 24, 144, 20>(cur, nxt, (char*)n->blob_body + i * blob,
                                                               n->cinit_body + (size_t)i * n->n_idx_cinit, n->N, n->H, n->W,

@@ -28,12 +28,14 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 // In-kernel time stamps exist only in the diagnostic build (-DSR_DEBUG_STAMPS -> libsr_hotpath_dbg.so, see
 // build.py); in the product library the macros are empty and no kernel carries a stamp pointer or a stamp load.
-// Layout: buf[workgroup][16 waves][16 stamps] of s_memrealtime (100 MHz), written by lane 0 of every wave.
+// Layout: buf[workgroup][16 waves][16 stamps][2] = {s_memrealtime (100 MHz), s_memtime (shader clock)}, written by
+// lane 0 of every wave: the pair gives both the wall time of a phase and the clock the chip held during it.
 #ifdef SR_DEBUG_STAMPS
 __device__ unsigned long long* g_sr_stamps = nullptr;
 #define SR_STAMP_DECL int stamp_i_ = 0
-#define SR_STAMP() do { unsigned long long* sp_ = g_sr_stamps; if (sp_ && (threadIdx.x & 63) == 0 && stamp_i_ < 16 && (threadIdx.x >> 6) < 16) \
-    sp_[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (threadIdx.x >> 6)) * 16 + stamp_i_] = __builtin_amdgcn_s_memrealtime(); ++stamp_i_; } while (0)
+#define SR_STAMP() do { unsigned long long* sp_ = g_sr_stamps; if (sp_ && (threadIdx.x & 63) == 0 && stamp_i_ < 16 && (threadIdx.x >> 6) < 16) { \
+    unsigned long long* q_ = sp_ + ((((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (threadIdx.x >> 6)) * 16 + stamp_i_) * 2; \
+    q_[0] = __builtin_amdgcn_s_memrealtime(); q_[1] = __builtin_amdgcn_s_memtime(); } ++stamp_i_; } while (0)
 #else
 #define SR_STAMP_DECL do {} while (0)
 #define SR_STAMP() do {} while (0)

@@ -713,11 +713,9 @@ __global__ __launch_bounds__((64 * WgradCfg<F, E, L, ROLE>::NWAVES)) void wdsr_b
 // =============================================================================================
 // two residual blocks per launch (bf16, F = 24): at batch 32 a block launch is bound by its fixed costs
 // (launch/drain ~2.7 us, staging ~1 us) rather than by bytes or flops, so block A is computed on the
-// tile + 1-pixel halo (from x on a 2-pixel halo) and handed to block B through LDS.  Block A's output
-// is still written once (core pixels) because backward needs every block input.  Results are bit-identical
-// to two wdsr_block_fwd_kernel launches.
-//   phase A1 (14 waves): t1 on the 16x28 region   phase B1 (12): y1 on the 14x26 region -> LDS (+ HBM core)
-//   phase A2 (12 waves): t2 on the 14x26 region   phase B2 ( 9): y2 on the 12x24 core -> HBM
+// tile + 1-pixel halo (from x on a 2-pixel halo) and handed to block B through LDS.  The forward pair lives
+// in wdsr_fwd_rs.h (register-resident weights); the geometry and the 3x3 / conv1-conv2 helpers below are shared
+// with the backward pair kernel.
 // =============================================================================================
 template <int F_, int E_, int L_> struct Pair {
   typedef BlockCfg<F_, E_, L_> C;
@@ -760,160 +758,6 @@ SR_DEV f32x16 y_from_t(const T* Timg, int trow, int tstride, const T* Ximg, int 
     oacc = mma16<T>(wsrc.get(C::W3_OFF + s, lane), *reinterpret_cast<const typename FragOf<T>::type*>(src), oacc);
   }
   return oacc;
-}
-
-template <typename T, int F, int E, int L>
-__global__ __launch_bounds__((64 * Pair<F, E, L>::NWAVES)) void wdsr_block2_fwd_kernel(
-    const T* __restrict__ x, T* __restrict__ ya, T* __restrict__ yb, const T* __restrict__ wa,
-    const T* __restrict__ wb, const float* __restrict__ cia, const float* __restrict__ cib, T* __restrict__ tsa,
-    T* __restrict__ tsb, int H, int W, int tiles_x) {
-  typedef BlockCfg<F, E, L> C;
-  typedef Pair<F, E, L> P;
-  typedef typename FragOf<T>::type FragT;
-  typedef typename FragOf<T>::half_type HalfT;
-  constexpr int NTHREADS = 64 * P::NWAVES;
-  __shared__ __attribute__((aligned(16))) T smem[P::LDS_ELEMS];
-  T* const XA = smem;
-  T* const TT = XA + P::XA_ELEMS;
-  T* const XB = TT + P::T_ELEMS;
-  T* const WL = XB + P::XB_ELEMS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-  const int n = blockIdx.y, tile = blockIdx.x;
-  const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
-  const size_t img = (size_t)n * H * W * F;
-  const size_t tile_g = (size_t)n * gridDim.x + tile;            // tile index of the saved t images
-  SR_STAMP_DECL;
-  SR_STAMP();
-
-  // ---- stage: both weight sets, x on the 2-pixel-halo region (zero outside the image, ones channel) ----
-  stage_weights<T, NTHREADS>(WL, wa, C::NFRAG_FWD, tid);
-  stage_weights<T, NTHREADS>(WL + P::W_ELEMS, wb, C::NFRAG_FWD, tid);
-  WSrc<T, true> wsa, wsb;
-  wsa.p = WL;
-  wsb.p = WL + P::W_ELEMS;
-  {
-    constexpr int CHX = C::KX / 8, TOTAL = P::NP2 * CHX, ITER = (TOTAL + NTHREADS - 1) / NTHREADS;
-    FragT v[ITER];
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const int idx = tid + it * NTHREADS;
-      const int hp = idx / CHX, c = idx - hp * CHX;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[it][j] = (T)0.f;
-      if (idx < TOTAL) {
-        if (c < C::FC) {
-          const int hy = hp / P::W2, hx = hp - hy * P::W2;
-          const int Y = ty0 - 2 + hy, X = tx0 - 2 + hx;
-          if (Y >= 0 && Y < H && X >= 0 && X < W) v[it] = *reinterpret_cast<const FragT*>(x + img + ((size_t)Y * W + X) * F + c * 8);
-        } else if (C::FOLD_B1 && c == C::FC) {
-          v[it][0] = (T)1.f;
-        }
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const int idx = tid + it * NTHREADS;
-      if (idx < TOTAL) *reinterpret_cast<FragT*>(XA + idx * 8) = v[it];
-    }
-    // block B's input image: zero, ones channel (phase B1 fills the F real channels of the live rows)
-    for (int idx = tid; idx < C::NPXH_PAD * CHX; idx += NTHREADS) {
-      FragT z;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) z[j] = (T)0.f;
-      if (C::FOLD_B1 && (idx % CHX) == C::FC) z[0] = (T)1.f;
-      *reinterpret_cast<FragT*>(XB + idx * 8) = z;
-    }
-  }
-  SR_STAMP();
-  __syncthreads();
-  SR_STAMP();
-
-  // ---- A1: t1 on the 16x28 region ----
-  {
-    const int hp2 = wave * 32 + r;
-    const int hy = hp2 / P::W2, hx = hp2 - hy * P::W2;
-    const int Y = ty0 - 2 + hy, X = tx0 - 2 + hx;
-    const bool valid = (Y >= 0 && Y < H && X >= 0 && X < W);
-    const f32x16 tacc = t_from_x<T, C>(XA, hp2, wsa, cia, lane);
-#pragma unroll
-    for (int g = 0; g < C::CPT; ++g) {
-      HalfT v = acc_group<T>(tacc, g);
-      if (!valid) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (T)0.f;
-      }
-      *reinterpret_cast<HalfT*>(TT + hp2 * C::LP + g * 8 + hh * 4) = v;
-      if (tsa && hy >= 2 && hy < 2 + C::TH && hx >= 2 && hx < 2 + C::TW)
-        stream_store(reinterpret_cast<HalfT*>(tsa + (tile_g * (C::TH * C::TW) + (hy - 2) * C::TW + hx - 2) * C::LP + g * 8 + hh * 4), v);
-    }
-  }
-  SR_STAMP();
-  __syncthreads();
-  SR_STAMP();
-
-  // ---- B1: y1 on the 14x26 region -> XB (and HBM for the core pixels) ----
-  if (wave < C::NPT_H) {
-    const int hp1 = wave * 32 + r;
-    const bool live = hp1 < C::NPXH;
-    const int hp1c = live ? hp1 : 0;
-    const int hy = hp1c / C::HW, hx = hp1c - hy * C::HW;
-    const f32x16 oacc = y_from_t<T, C>(TT, hy * P::W2 + hx, P::W2, XA, (hy + 1) * P::W2 + hx + 1, wsa, lane);
-    if (live) {
-#pragma unroll
-      for (int g = 0; g < C::FC; ++g) *reinterpret_cast<HalfT*>(XB + hp1 * C::KX + g * 8 + hh * 4) = acc_group<T>(oacc, g);
-      const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
-      if (ya && hy >= 1 && hy <= C::TH && hx >= 1 && hx <= C::TW && Y < H && X < W) {
-        T* o = ya + img + ((size_t)Y * W + X) * F;
-#pragma unroll
-        for (int g = 0; g < C::FC; ++g) stream_store(reinterpret_cast<HalfT*>(o + g * 8 + hh * 4), acc_group<T>(oacc, g));
-      }
-    }
-  }
-  SR_STAMP();
-  __syncthreads();
-  SR_STAMP();
-
-  // ---- A2: t2 on the 14x26 region (over the t1 image) ----
-  if (wave < C::NPT_H) {
-    const int hp1 = wave * 32 + r;
-    bool valid = false;
-    if (hp1 < C::NPXH) {
-      const int hy = hp1 / C::HW, hx = hp1 - hy * C::HW;
-      const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
-      valid = (Y >= 0 && Y < H && X >= 0 && X < W);
-    }
-    const f32x16 tacc = t_from_x<T, C>(XB, hp1, wsb, cib, lane);
-    const int hy1 = hp1 / C::HW, hx1 = hp1 - hy1 * C::HW;
-    const bool core = tsb && hp1 < C::NPXH && hy1 >= 1 && hy1 <= C::TH && hx1 >= 1 && hx1 <= C::TW;
-#pragma unroll
-    for (int g = 0; g < C::CPT; ++g) {
-      HalfT v = acc_group<T>(tacc, g);
-      if (!valid) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (T)0.f;
-      }
-      *reinterpret_cast<HalfT*>(TT + hp1 * C::LP + g * 8 + hh * 4) = v;
-      if (core)
-        stream_store(reinterpret_cast<HalfT*>(tsb + (tile_g * (C::TH * C::TW) + (hy1 - 1) * C::TW + hx1 - 1) * C::LP + g * 8 + hh * 4), v);
-    }
-  }
-  SR_STAMP();
-  __syncthreads();
-  SR_STAMP();
-
-  // ---- B2: y2 on the core ----
-  if (wave < C::NPT_O) {
-    const int ot = wave;
-    const int oy = (ot / (C::TW / 8)) * 4 + (r >> 3), ox = (ot % (C::TW / 8)) * 8 + (r & 7);
-    const f32x16 oacc = y_from_t<T, C>(TT, oy * C::HW + ox, C::HW, XB, (oy + 1) * C::HW + ox + 1, wsb, lane);
-    const int Y = ty0 + oy, X = tx0 + ox;
-    if (Y < H && X < W) {
-      T* o = yb + img + ((size_t)Y * W + X) * F;
-#pragma unroll
-      for (int g = 0; g < C::FC; ++g) stream_store(reinterpret_cast<HalfT*>(o + g * 8 + hh * 4), acc_group<T>(oacc, g));
-    }
-  }
-  SR_STAMP();
 }
 
 // =============================================================================================

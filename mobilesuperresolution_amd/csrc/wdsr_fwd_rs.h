@@ -1,0 +1,453 @@
+// Forward of one or two fused WDSR-B residual blocks with REGISTER-RESIDENT weights (bf16, gfx950).
+// Reference op: Block.forward, models/basic_wdsr_b.py:108-144, applied NBLK times.
+//
+// Why a second forward design (measured on MI355X: per-wave stamps of the diagnostic build, tools/ubench/*):
+//   * the one-tile-per-wave kernels of wdsr_block.h read BOTH operands of every MFMA from LDS (1 KiB each); the LDS
+//     delivers 256 B/clk per CU and the four SIMDs can take one 32x32x16 MFMA per 8 clk between them, so those
+//     kernels need all of the LDS bandwidth to reach the matrix rate and sit at ~45 % of either.  Here every wave
+//     keeps the weights of its current phase in registers (conv1 + conv2: 76 VGPRs, 3x3: 60 at 24 units) and
+//     only the pixel operand (x, t) and the t / y hand-off go through LDS;
+//   * a lone wave can issue ~4 VALU ops per MFMA for free and pays 8 cycles for every further one, and the
+//     convert + ReLU between conv1 and conv2 is exactly 4 per MFMA: the products are issued in the order
+//     G1a(et+1) cvt G1b(et+1) relu G2b(et-1) cvt G2a(et) relu (sched_group_barrier pins it), two waves per SIMD
+//     run the same phase so that one wave's remaining VALU work (addresses, masks, stores) hides under the other's
+//     MFMAs, and per-tile bookkeeping is hoisted out of the MFMA stream;
+//   * everything that comes from HBM / L2 is staged by LDS-DMA (no registers, no per-iteration wait): the weights
+//     as they lie, the halo'd x tile by per-lane source addresses, with two 16-byte constants standing in for the
+//     zero padding and for the "ones" channel that carries conv1's bias.
+// Products, k-order and roundings are those of wdsr_block_fwd_kernel: results are bit-identical to it.
+#pragma once
+#include "wdsr_block.h"
+
+// 16-byte chunks the staging DMA reads for lanes without pixel data: [0..7] = ones chunk (bf16 1.0, then
+// zeros), [8..15] = zeros
+__device__ __attribute__((aligned(16))) const unsigned short g_sr_const_chunks[16] = {0x3F80, 0, 0, 0, 0, 0, 0, 0,
+                                                                                      0,      0, 0, 0, 0, 0, 0, 0};
+
+template <int F_, int E_, int L_, int NBLK_> struct RsCfg {
+  typedef BlockCfg<F_, E_, L_> C;
+  static constexpr int NBLK = NBLK_, NWAVES = 8, NTHREADS = 64 * NWAVES;
+  // region k (k = 0 .. NBLK): the tile plus a halo of NBLK - k pixels; block k maps region k -> region k + 1
+  static constexpr int rw(int k) { return C::TW + 2 * (NBLK - k); }
+  static constexpr int rh(int k) { return C::TH + 2 * (NBLK - k); }
+  static constexpr int np(int k) { return rw(k) * rh(k); }
+  static constexpr int npad(int k) { return (np(k) + 31) / 32 * 32; }
+  // LDS rows of the block inputs hold the F real channels only (48 bytes at 24 units: a conflict-free stride for
+  // 16-byte reads, where the 64-byte rows of wdsr_block.h are 4-way conflicted for reads and 8-way for the 8-byte
+  // hand-off stores: 67 % of the LDS-active cycles of phase B were conflicts); the "ones" chunk that carries conv1's
+  // bias is ONE 16-byte constant in LDS that every lane half needing it reads (a broadcast)
+  static constexpr int KXL = C::F;
+  static constexpr int X0_ELEMS = npad(0) * KXL;                       // staged x
+  static constexpr int TT_ELEMS = npad(0) * C::LP;                     // t of the current block
+  static constexpr int X1_ELEMS = NBLK > 1 ? npad(1) * KXL : 0;        // block 0's output = block 1's input
+  static constexpr int ONES_ELEMS = 8;
+  static constexpr int W_ELEMS = C::NFRAG_FWD * 512;
+  static constexpr int CL_FLOATS = (C::CINIT_FWD + 3) / 4 * 4;
+  static constexpr int LDS_BYTES = (X0_ELEMS + TT_ELEMS + X1_ELEMS + NBLK * W_ELEMS + ONES_ELEMS) * 2 + NBLK * CL_FLOATS * 4;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+// stage rows [0, NROWS) of an LDS image [NROWS][F] by LDS-DMA: row p < NLIVE is pixel (y0 + p / RW, x0 + p % RW) of
+// the NHWC image `img`, zero outside the image (the lanes concerned read a 16-byte constant instead).
+template <typename C, int RW, int NLIVE, int NROWS, int NTHREADS>
+SR_DEV void stage_region_dma(__bf16* dst, const __bf16* __restrict__ img, int H, int W, int y0, int x0, int tid) {
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  constexpr int CH = C::FC, TOTAL = NROWS * CH, NW = NTHREADS / 64;
+  static_assert(TOTAL % 64 == 0, "whole 1 KiB pieces");
+  const int lane = tid & 63, wave = tid >> 6;
+  const char* zeros = reinterpret_cast<const char*>(g_sr_const_chunks) + 16;
+  for (int piece = wave; piece < TOTAL / 64; piece += NW) {
+    const int c = piece * 64 + lane;
+    const int p = c / CH, ch = c - p * CH;
+    const int py = p / RW, px = p - py * RW;
+    const int Y = y0 + py, X = x0 + px;
+    const char* src = zeros;
+    if (p < NLIVE && Y >= 0 && Y < H && X >= 0 && X < W) src = reinterpret_cast<const char*>(img + ((size_t)Y * W + X) * C::F + ch * 8);
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(reinterpret_cast<char*>(dst) + piece * 1024), 16, 0, 0);
+  }
+}
+
+// register-resident weights of one phase
+template <typename C> struct RwA {
+  bf16x8 w1[C::NET * C::KS1], w2[C::KS2];
+  SR_DEV void load(const __bf16* wl, int lane) {
+#pragma unroll
+    for (int i = 0; i < C::NET * C::KS1; ++i) w1[i] = lds_chunk<__bf16>(wl, ((C::W1_OFF + i) * 64 + lane) * 8);
+#pragma unroll
+    for (int i = 0; i < C::KS2; ++i) w2[i] = lds_chunk<__bf16>(wl, ((C::W2_OFF + i) * 64 + lane) * 8);
+  }
+};
+template <typename C> struct RwB {
+  bf16x8 w3[C::KS3];
+  SR_DEV void load(const __bf16* wl, int lane) {
+#pragma unroll
+    for (int i = 0; i < C::KS3; ++i) w3[i] = lds_chunk<__bf16>(wl, ((C::W3_OFF + i) * 64 + lane) * 8);
+  }
+};
+
+// t^T for one 32-pixel tile, written in the order one wave should issue it: per e-tile
+//   G1a(et+1) | cvt f0(et) | G1b(et+1) | relu f0(et) | G2b(et-1) | cvt f1(et) | G2a(et) | relu f1(et)
+// i.e. four MFMAs with four VALU ops in each gap, every MFMA independent of the VALU ops right before it, and no
+// VALU op closer than two MFMAs behind the product it reads.  The conv2 accumulation order (a0, b0, a1, b1, ...)
+// is that of t_from_xb: bit-identical results.
+template <typename C>
+SR_DEV f32x16 rw_t_tile(const bf16x8 (&xb)[C::KS1], const RwA<C>& w, const float* cl, int hh) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  // b2 and the ones channel of t, straight from the LDS table into the accumulator (4 broadcast reads; held in
+  // registers it would cost 16 VGPRs and 16 copies per tile)
+  f32x16 tacc = load_cinit(cl, hh);
+  auto conv1_step = [&](f32x16 acc, int et, int s) { return mma16<__bf16>(w.w1[et * C::KS1 + s], xb[s], acc); };
+  auto conv1_init = [&](int et) { return C::FOLD_B1 ? zero16() : load_cinit(cl + 32 + et * 32, hh); };
+  auto cvt4 = [&](const f32x16& a, int base) {       // regs base..base+7 -> 4 packed dwords (no ReLU yet)
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      __bf16 lo, hi;
+      cvt_pair<__bf16>(lo, hi, a[base + j], a[base + j + 1]);
+      f[j] = lo;
+      f[j + 1] = hi;
+    }
+    return f;
+  };
+  auto relu8 = [&](bf16x8 f) {
+    s16x8 v = __builtin_bit_cast(s16x8, f);
+    const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_bit_cast(bf16x8, __builtin_elementwise_max(v, z));
+  };
+  static_assert(C::KS1 == 2, "two conv1 k-steps per e-tile");
+  f32x16 h = conv1_init(0);
+  h = conv1_step(h, 0, 0);
+  h = conv1_step(h, 0, 1);
+  bf16x8 f1prev = {};
+#pragma unroll
+  for (int et = 0; et < C::NET; ++et) {
+    const bool more = et + 1 < C::NET;
+    f32x16 hn = h;
+    if (more) hn = conv1_step(conv1_init(et + 1), et + 1, 0);                                   // MFMA
+    bf16x8 f0 = cvt4(h, 0);                                                                     // 4 VALU
+    if (more) hn = conv1_step(hn, et + 1, 1);                                                   // MFMA
+    f0 = relu8(f0);                                                                             // 4 VALU
+    if (et > 0 && 2 * (et - 1) + 1 < C::KS2) tacc = mma16<__bf16>(w.w2[2 * et - 1], f1prev, tacc);   // MFMA
+    bf16x8 f1 = cvt4(h, 8);                                                                     // 4 VALU
+    if (2 * et < C::KS2) tacc = mma16<__bf16>(w.w2[2 * et], f0, tacc);                          // MFMA
+    f1prev = relu8(f1);                                                                         // 4 VALU
+    h = hn;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);    // 4 VALU
+    }
+  }
+  if (2 * (C::NET - 1) + 1 < C::KS2) tacc = mma16<__bf16>(w.w2[2 * C::NET - 1], f1prev, tacc);
+  return tacc;
+}
+
+// per-lane description of one pixel of a phase-A tile, computed BEFORE the MFMA stream starts
+struct RwPix {
+  int hp;        // row of the x / t images
+  int tso;       // element offset in the saved-t tile, -1 = not a core pixel
+  bool valid;    // inside the image (t is zero elsewhere)
+};
+template <typename C, int RW, int NP, int HALO>
+SR_DEV RwPix rw_pix_a(int hp, int H, int W, int ty0, int tx0) {
+  RwPix p;
+  p.hp = hp;
+  const int hy = hp / RW, hx = hp - hy * RW;
+  const int Y = ty0 - HALO + hy, X = tx0 - HALO + hx;
+  p.valid = hp < NP && Y >= 0 && Y < H && X >= 0 && X < W;
+  const bool core = hp < NP && hy >= HALO && hy < HALO + C::TH && hx >= HALO && hx < HALO + C::TW;
+  p.tso = core ? ((hy - HALO) * C::TW + hx - HALO) * C::LP : -1;
+  return p;
+}
+template <typename C, bool SAVE_T>
+SR_DEV void rw_store_t(const f32x16& tacc, const RwPix& p, __bf16* TT, __bf16* tsave_tile, int hh) {
+  bf16x4 v[C::CPT];
+#pragma unroll
+  for (int g = 0; g < C::CPT; ++g) {
+    v[g] = acc_group<__bf16>(tacc, g);
+    if (!p.valid) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[g][j] = (__bf16)0.f;
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < C::CPT; ++g) *reinterpret_cast<bf16x4*>(TT + p.hp * C::LP + g * 8 + hh * 4) = v[g];
+  if constexpr (SAVE_T) {
+    if (p.tso >= 0) {
+#pragma unroll
+      for (int g = 0; g < C::CPT; ++g) stream_store(reinterpret_cast<bf16x4*>(tsave_tile + p.tso + g * 8 + hh * 4), v[g]);
+    }
+  }
+}
+
+// x fragments of one pixel row for conv1: chunk q = 2 s + hh of the F real channels, or the ones chunk behind them
+template <typename C, int KXL>
+SR_DEV void rw_x_frags(bf16x8 (&xb)[C::KS1], const __bf16* Xin, const __bf16* ones, int hp, int hh) {
+#pragma unroll
+  for (int s = 0; s < C::KS1; ++s) {
+    const int q = 2 * s + hh;
+    const __bf16* src = Xin + hp * KXL + q * 8;
+    if (C::FOLD_B1 && 2 * s + 1 >= C::FC) src = q < C::FC ? src : ones;     // (per-lane select only where a half can leave the row)
+    xb[s] = *reinterpret_cast<const bf16x8*>(src);
+  }
+}
+
+// phase A of one block over a region (RW wide, NP pixels, HALO around the tile): t -> TT.  Every wave takes tile
+// `wave` and, if there is one, tile `wave + NW`.  `prefetch()` is called once the wave's own operand reads are
+// issued: the next phase's weights travel LDS -> registers underneath this phase's MFMAs.
+template <typename C, int KXL, int RW, int NP, int HALO, int NW, bool SAVE_T, typename PF>
+SR_DEV void rw_phase_a(const __bf16* Xin, const __bf16* ones, __bf16* TT, const RwA<C>& w, const float* cl, __bf16* tsave_tile,
+                       int H, int W, int ty0, int tx0, int wave, int lane, PF prefetch) {
+  constexpr int NT = (NP + 31) / 32;
+  const int r = lane & 31, hh = lane >> 5;
+  if (wave >= NT) {                                    // wave-uniform
+    prefetch();
+    return;
+  }
+  RwPix p = rw_pix_a<C, RW, NP, HALO>(wave * 32 + r, H, W, ty0, tx0);
+  bf16x8 xb[C::KS1];
+  rw_x_frags<C, KXL>(xb, Xin, ones, p.hp, hh);
+  prefetch();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+  for (int tile = wave; tile < NT; tile += NW) {
+    const f32x16 t = rw_t_tile<C>(xb, w, cl, hh);
+    const RwPix pc = p;
+    if (tile + NW < NT) {                              // the next tile's operands land while this one is converted and stored
+      p = rw_pix_a<C, RW, NP, HALO>((tile + NW) * 32 + r, H, W, ty0, tx0);
+      rw_x_frags<C, KXL>(xb, Xin, ones, p.hp, hh);
+    }
+    rw_store_t<C, SAVE_T>(t, pc, TT, tsave_tile, hh);
+  }
+}
+
+// Pixel operands of the 3x3 conv.  Chunk q = 2 s + hh of k-step s is (tap, 8 channels) for q < 9 CPT and a chunk of
+// the block input (residual) after that.  A t row holds exactly CPT chunks per pixel, so the 3 CPT chunks of one
+// kernel row ky are CONSECUTIVE 16-byte pieces starting at pixel (trow + ky RWI): with the lane-half offset folded
+// into the base, every fragment is `base + constant` except the two k-steps whose halves straddle a row change.
+// Four per-lane bases, zero address arithmetic per read.
+template <typename C, int KXL, int RWI> struct RwBAddr {
+  static constexpr int ROWQ = 3 * C::CPT;                   // chunks per kernel row
+  static constexpr int NQ = 9 * C::CPT;                     // t chunks in all
+  const __bf16* bt;       // t image at (trow), + hh chunk
+  const __bf16* bx;       // x image at (xrow), + hh chunk
+  const __bf16* bsplit[2];
+  static constexpr int off_q(int q) {                        // element offset of chunk q from the UN-shifted bases; x chunks: from bx
+    return q < NQ ? (q / ROWQ) * RWI * C::LP + (q % ROWQ) * 8 : ((q - NQ) < C::FC ? (q - NQ) : 0) * 8;
+  }
+  static constexpr bool split(int s) {                       // halves not 8 elements apart in one image
+    const int q0 = 2 * s, q1 = 2 * s + 1;
+    if (q1 >= NQ + C::FC) return true;                       // padded chunk (hh = 1 reads x chunk 0)
+    if ((q0 < NQ) != (q1 < NQ)) return true;
+    return off_q(q1) - off_q(q0) != 8;
+  }
+  SR_DEV void init(const __bf16* TT, const __bf16* Xin, int hy, int hx, int hh) {
+    const __bf16* t0 = TT + (hy * RWI + hx) * C::LP;
+    const __bf16* x0 = Xin + ((hy + 1) * RWI + hx + 1) * KXL;
+    bt = t0 + hh * 8;
+    bx = x0 + hh * 8;
+    int k = 0;
+#pragma unroll
+    for (int s = 0; s < C::KS3; ++s) {
+      if (split(s)) {
+        const int q0 = 2 * s, q1 = 2 * s + 1;
+        const __bf16* a0 = (q0 < NQ ? t0 : x0) + off_q(q0);
+        const __bf16* a1 = (q1 < NQ ? t0 : x0) + off_q(q1);
+        if (k < 2) bsplit[k] = hh ? a1 : a0;
+        ++k;
+      }
+    }
+  }
+  static constexpr int nsplit() {
+    int k = 0;
+    for (int s = 0; s < C::KS3; ++s) k += split(s) ? 1 : 0;
+    return k;
+  }
+  SR_DEV bf16x8 frag(int s) const {
+    if (split(s)) {
+      int k = 0;
+      for (int i = 0; i < s; ++i) k += split(i) ? 1 : 0;
+      return *reinterpret_cast<const bf16x8*>(bsplit[k]);
+    }
+    const int q0 = 2 * s;
+    return *reinterpret_cast<const bf16x8*>((q0 < NQ ? bt : bx) + off_q(q0));
+  }
+};
+
+struct RwPixB {
+  int hy, hx;
+  int xno;          // element offset of this pixel's row in the next block's input image
+  unsigned go;      // byte offset in the global output image, out of range (dropped by the bounds check) = do not store
+};
+template <typename C, int KXL, int RWO, int NPO, int HALOO>
+SR_DEV RwPixB rw_pix_b(int tile, int r, int H, int W, int ty0, int tx0) {
+  RwPixB p;
+  int hp;
+  if constexpr (HALOO == 0) {                         // core: 4 x 8 pixel tiles (the layout the saved images use)
+    p.hy = (tile / (C::TW / 8)) * 4 + (r >> 3);
+    p.hx = (tile % (C::TW / 8)) * 8 + (r & 7);
+    hp = p.hy * RWO + p.hx;
+  } else {
+    hp = tile * 32 + r;
+    const int hpc = hp < NPO ? hp : 0;                // rows past the region: compute something finite, store it in the slack rows
+    p.hy = hpc / RWO;
+    p.hx = hpc - p.hy * RWO;
+  }
+  p.xno = hp * KXL;
+  const int Y = ty0 - HALOO + p.hy, X = tx0 - HALOO + p.hx;
+  const bool st = hp < NPO && p.hy >= HALOO && p.hy < HALOO + C::TH && p.hx >= HALOO && p.hx < HALOO + C::TW && Y < H && X < W;
+  p.go = st ? (unsigned)((Y * W + X) * C::F * 2) : 0xFFFFFF00u;
+  return p;
+}
+// y of one tile: LDS hand-off to the next block (every lane: rows past the region land in the image's slack rows)
+// and / or the global store of the core pixels.  The global store is a buffer store whose offset is out of range
+// for the lanes that must not store (the bounds check drops them): no branch, so the stores can sit in the middle
+// of the next tile's MFMA chain.
+template <typename C>
+SR_DEV void rw_store_y(const f32x16& oacc, const RwPixB& p, __bf16* Xnext, __amdgpu_buffer_rsrc_t yrs, bool to_global, int hh) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
+  bf16x4 v[C::FC];
+#pragma unroll
+  for (int g = 0; g < C::FC; ++g) v[g] = acc_group<__bf16>(oacc, g);
+  if (Xnext) {
+#pragma unroll
+    for (int g = 0; g < C::FC; ++g) *reinterpret_cast<bf16x4*>(Xnext + p.xno + g * 8 + hh * 4) = v[g];
+  }
+  if (to_global) {
+    const unsigned off = p.go + hh * 8;
+#pragma unroll
+    for (int g = 0; g < C::FC; ++g)
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, v[g]), yrs, off + g * 16, 0, 2 /* nt */);
+  }
+}
+
+// One 3x3 chain: (MFMA, read) pairs in source order, pinned by sched_barrier: the pixel operand of k-step s + AHEAD is
+// requested right after the MFMA of k-step s (a 3x3 chain is one dependent accumulation, which issues back to back at
+// full rate).  `mid()` runs LAG MFMAs into the chain: the previous tile's stores go there.
+template <typename C, typename A, int AHEAD, int LAG, typename MID>
+SR_DEV f32x16 rw_b_chain(const A& a, const RwB<C>& w, MID mid) {
+  constexpr int KS3 = C::KS3;
+  bf16x8 f[KS3];
+#pragma unroll
+  for (int s = 0; s < AHEAD; ++s) f[s] = a.frag(s);
+  f32x16 acc = zero16();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < KS3; ++s) {
+    acc = mma16<__bf16>(w.w3[s], f[s], acc);
+    if (s + AHEAD < KS3) f[s + AHEAD] = a.frag(s + AHEAD);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s == LAG) {
+      mid();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  return acc;
+}
+
+template <typename C, int KXL, int RWO, int NPO, int HALOO, int NW, typename PF>
+SR_DEV void rw_phase_b(const __bf16* TT, const __bf16* Xin, __bf16* Xnext, __bf16* yout, const RwB<C>& w, int H, int W, int ty0,
+                       int tx0, int wave, int lane, PF prefetch) {
+  constexpr int NT = (NPO + 31) / 32, RWI = RWO + 2, AHEAD = 4, LAG = 4;
+  typedef RwBAddr<C, KXL, RWI> A;
+  static_assert(A::nsplit() <= 2, "two straddling k-steps at most");
+  const int r = lane & 31, hh = lane >> 5;
+  if (wave >= NT) {                                    // wave-uniform
+    prefetch();
+    return;
+  }
+  const bool to_global = yout != nullptr;
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yout, 0, to_global ? H * W * C::F * 2 : 0, 0x00020000);
+  RwPixB p = rw_pix_b<C, KXL, RWO, NPO, HALOO>(wave, r, H, W, ty0, tx0);
+  A a;
+  a.init(TT, Xin, p.hy, p.hx, hh);
+  // first tile: nothing to store yet; the next phase's weights are requested behind its first reads
+  f32x16 acc = rw_b_chain<C, A, AHEAD, LAG>(a, w, [&] { prefetch(); });
+#pragma unroll 1
+  for (int tile = wave + NW; tile < NT; tile += NW) {
+    const RwPixB pp = p;
+    const f32x16 pacc = acc;
+    p = rw_pix_b<C, KXL, RWO, NPO, HALOO>(tile, r, H, W, ty0, tx0);
+    a.init(TT, Xin, p.hy, p.hx, hh);
+    acc = rw_b_chain<C, A, AHEAD, LAG>(a, w, [&] { rw_store_y<C>(pacc, pp, Xnext, yrs, to_global, hh); });
+  }
+  rw_store_y<C>(acc, p, Xnext, yrs, to_global, hh);
+}
+
+// grid = (tiles_y * tiles_x, N), 512 threads.  NBLK = 1: x -> yb (ya, wb, cib, tsb unused).  NBLK = 2: x -> ya (block
+// A's output, nullptr = not stored) -> yb.  tsa / tsb (SAVE_T): saved t images, [N][tiles][288][LP].
+template <int F, int E, int L, int NBLK, bool SAVE_T>
+__global__ __launch_bounds__(512) void wdsr_fwd_rs_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ ya,
+                                                          __bf16* __restrict__ yb, const __bf16* __restrict__ wa,
+                                                          const __bf16* __restrict__ wb, const float* __restrict__ cia,
+                                                          const float* __restrict__ cib, __bf16* __restrict__ tsa,
+                                                          __bf16* __restrict__ tsb, int H, int W, int tiles_x) {
+  typedef BlockCfg<F, E, L> C;
+  typedef RsCfg<F, E, L, NBLK> R;
+  constexpr int NTHREADS = R::NTHREADS, NW = R::NWAVES;
+  __shared__ __attribute__((aligned(16))) char smem_raw[R::LDS_BYTES];
+  __bf16* const X0 = reinterpret_cast<__bf16*>(smem_raw);
+  __bf16* const TT = X0 + R::X0_ELEMS;
+  __bf16* const X1 = TT + R::TT_ELEMS;
+  __bf16* const WL = X1 + R::X1_ELEMS;
+  __bf16* const ONES = WL + NBLK * R::W_ELEMS;
+  float* const CL = reinterpret_cast<float*>(ONES + R::ONES_ELEMS);
+  constexpr int KXL = R::KXL;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // provably wave-uniform: scalar branches
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+  const size_t img = (size_t)n * H * W * F;
+  const size_t tile_g = (size_t)n * gridDim.x + tile;
+  SR_STAMP_DECL;
+  SR_STAMP();
+
+  // ---- stage: x on the halo'd region, every weight fragment, the C-init tables ----
+  float civ = 0.f;                                                      // issued first, written to LDS last: one wait in all
+  if (tid < C::CINIT_FWD) civ = cia[tid];
+  if constexpr (NBLK > 1) {
+    if (tid >= 256 && tid < 256 + C::CINIT_FWD) civ = cib[tid - 256];
+  }
+  stage_region_dma<C, R::rw(0), R::np(0), R::npad(0), NTHREADS>(X0, x + img, H, W, ty0 - NBLK, tx0 - NBLK, tid);
+  stage_weights<__bf16, NTHREADS>(WL, wa, C::NFRAG_FWD, tid);
+  if constexpr (NBLK > 1) stage_weights<__bf16, NTHREADS>(WL + R::W_ELEMS, wb, C::NFRAG_FWD, tid);
+  if (tid < 8) ONES[tid] = tid == 0 ? (__bf16)1.f : (__bf16)0.f;
+  static_assert(C::CINIT_FWD <= 256, "one C-init float per thread");
+  if (tid < C::CINIT_FWD) CL[tid] = civ;
+  if constexpr (NBLK > 1) {
+    if (tid >= 256 && tid < 256 + C::CINIT_FWD) CL[R::CL_FLOATS + tid - 256] = civ;
+  }
+  SR_STAMP();
+  __syncthreads();
+  SR_STAMP();
+
+  __bf16* const tsa_tile = SAVE_T ? tsa + tile_g * (C::TH * C::TW) * C::LP : nullptr;
+  __bf16* const tsb_tile = (SAVE_T && NBLK > 1) ? tsb + tile_g * (C::TH * C::TW) * C::LP : nullptr;
+  RwA<C> rwa;
+  RwB<C> rwb;
+  rwa.load(WL, lane);
+  // ---- block 0 ----
+  rw_phase_a<C, KXL, R::rw(0), R::np(0), NBLK, NW, SAVE_T>(X0, ONES, TT, rwa, CL, tsa_tile, H, W, ty0, tx0, wave, lane,
+                                                             [&] { rwb.load(WL, lane); });
+  SR_STAMP();
+  __syncthreads();
+  SR_STAMP();
+  if constexpr (NBLK == 1) {
+    rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NW>(TT, X0, nullptr, yb + img, rwb, H, W, ty0, tx0, wave, lane, [] {});
+  } else {
+    rw_phase_b<C, KXL, R::rw(1), R::np(1), NBLK - 1, NW>(TT, X0, X1, ya ? ya + img : nullptr, rwb, H, W, ty0, tx0, wave, lane,
+                                                         [&] { rwa.load(WL + R::W_ELEMS, lane); });
+    SR_STAMP();
+    __syncthreads();
+    SR_STAMP();
+    // ---- block 1 ----
+    rw_phase_a<C, KXL, R::rw(1), R::np(1), NBLK - 1, NW, SAVE_T>(X1, ONES, TT, rwa, CL + R::CL_FLOATS, tsb_tile, H, W, ty0, tx0, wave,
+                                                                 lane, [&] { rwb.load(WL + R::W_ELEMS, lane); });
+    SR_STAMP();
+    __syncthreads();
+    SR_STAMP();
+    rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NW>(TT, X1, nullptr, yb + img, rwb, H, W, ty0, tx0, wave, lane, [] {});
+  }
+  SR_STAMP();
+}

@@ -190,6 +190,51 @@ def test_block_pair_kernel_bit_identical_to_two_launches(shape):
     assert torch.equal(p1, y1) and torch.equal(p2, y2)
 
 
+@pytest.mark.parametrize("f,nblk", [(24, 1), (24, 2)])
+@pytest.mark.parametrize("shape", [(3, 48, 48), (2, 20, 28), (1, 7, 9), (2, 37, 91)])
+def test_role_specialised_forward_bit_identical(shape, f, nblk):
+    """sr_wdsr_fwd_rs (register-resident weights per wave role, LDS-DMA staging) == sr_wdsr_block_fwd launches, bit
+    for bit: block outputs and the saved t images, ragged tiles and images smaller than one tile included"""
+    from mobilesuperresolution_amd import _lib as L, hotpath as HP
+    n, h, w = shape
+    g = torch.Generator().manual_seed(23)
+    src = (torch.randn(2, HP.tables(f, torch.device("cuda", 0))["src_size"], generator=g) * 0.08).cuda()
+    src[:, -2], src[:, -1] = 0.0, 1.0
+    blob, cinit = HP.pack_blocks(src, f, torch.bfloat16)
+    x = torch.randn(n, h, w, f, generator=g).cuda().bfloat16()
+    tiles = ((h + 11) // 12) * ((w + 23) // 24)
+    lp = 24 if f == 24 else 32
+    lib = L.lib()
+    # reference: the single-block kernel through the whole-net "save" path's building block (keeps t as well)
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    HP.block_fwd(x, y1, blob[0], cinit[0])
+    HP.block_fwd(y1, y2, blob[1], cinit[1])
+    p1, p2 = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+    ts = torch.full((2, n, tiles, 288, lp), float("nan"), device="cuda", dtype=torch.bfloat16)
+    if nblk == 2:
+        L.check(lib.sr_wdsr_fwd_rs(x.data_ptr(), p1.data_ptr(), p2.data_ptr(), blob[0].data_ptr(), blob[1].data_ptr(),
+                                   cinit[0].data_ptr(), cinit[1].data_ptr(), ts[0].data_ptr(), ts[1].data_ptr(), 2, n, h, w, f, 1,
+                                   L.stream_ptr()), "rs2")
+    else:
+        L.check(lib.sr_wdsr_fwd_rs(x.data_ptr(), None, p1.data_ptr(), blob[0].data_ptr(), None, cinit[0].data_ptr(), None,
+                                   ts[0].data_ptr(), None, 1, n, h, w, f, 1, L.stream_ptr()), "rs1a")
+        L.check(lib.sr_wdsr_fwd_rs(p1.data_ptr(), None, p2.data_ptr(), blob[1].data_ptr(), None, cinit[1].data_ptr(), None,
+                                   ts[1].data_ptr(), None, 1, n, h, w, f, 1, L.stream_ptr()), "rs1b")
+    torch.cuda.synchronize()
+    assert torch.equal(p1, y1) and torch.equal(p2, y2)
+    # saved t images: one-block and two-block launches must keep the same t (the weight-gradient tests check t itself
+    # against the recompute kernels)
+    if nblk == 2:
+        ts1 = torch.full_like(ts, float("nan"))
+        q1, q2 = torch.empty_like(x), torch.empty_like(x)
+        L.check(lib.sr_wdsr_fwd_rs(x.data_ptr(), None, q1.data_ptr(), blob[0].data_ptr(), None, cinit[0].data_ptr(), None,
+                                   ts1[0].data_ptr(), None, 1, n, h, w, f, 1, L.stream_ptr()), "rs1a")
+        L.check(lib.sr_wdsr_fwd_rs(q1.data_ptr(), None, q2.data_ptr(), blob[1].data_ptr(), None, cinit[1].data_ptr(), None,
+                                   ts1[1].data_ptr(), None, 1, n, h, w, f, 1, L.stream_ptr()), "rs1b")
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(ts, nan=-7.0), torch.nan_to_num(ts1, nan=-7.0))
+
+
 @pytest.mark.parametrize("shape", [(3, 48, 48), (2, 20, 28), (1, 7, 9)])
 def test_block_pair_bwd_data_bit_identical_to_two_launches(shape):
     """sr_wdsr_block2_bwd_data == two sr_wdsr_block_bwd_data launches, bit for bit (incl. ragged tiles)"""

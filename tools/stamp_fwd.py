@@ -15,10 +15,14 @@ blob, cinit = HP.pack_blocks(src, f, torch.bfloat16)
 x = torch.randn(n, 48, 48, f, device="cuda").bfloat16()
 ya = torch.empty_like(x); yb = torch.empty_like(x)
 nwg = n * 8
-st = torch.zeros(nwg * 16 * 16, dtype=torch.int64, device="cuda")
+st = torch.zeros(nwg * 16 * 16 * 2, dtype=torch.int64, device="cuda")
 lib = L.lib()
 def run():
-    if mode == "pair":
+    if mode in ("rs1", "rs2"):
+        nb = int(mode[2])
+        L.check(lib.sr_wdsr_fwd_rs(x.data_ptr(), ya.data_ptr(), yb.data_ptr(), blob[0].data_ptr(), blob[1].data_ptr(),
+                                   cinit[0].data_ptr(), cinit[1].data_ptr(), None, None, nb, n, 48, 48, f, 1, L.stream_ptr()), "rs")
+    elif mode == "pair":
         L.check(lib.sr_wdsr_block2_fwd(x.data_ptr(), ya.data_ptr(), yb.data_ptr(), blob[0].data_ptr(), blob[1].data_ptr(),
                                        cinit[0].data_ptr(), cinit[1].data_ptr(), None, None, n, 48, 48, f, 1, L.stream_ptr()), "pair")
     else:
@@ -32,13 +36,15 @@ for it in range(3):
     run()
 torch.cuda.synchronize()
 L.check(lib.sr_debug_set_stamps(None), "unset")
-s = st.cpu().numpy().reshape(nwg, 16, 16).astype(np.float64) * 10.0      # ns (100 MHz)
+raw = st.cpu().numpy().reshape(nwg, 16, 16, 2).astype(np.float64)
+s = raw[..., 0] * 10.0                                                    # ns (100 MHz)
+cyc = raw[..., 1]
 nst = int((s[0, 0] > 0).sum())
 nw = int((s[0, :, 0] > 0).sum())
 t0 = s[:, :nw, 0].min()
 print(f"{mode} batch {n}: {nwg} workgroups, {nw} waves, {nst} stamps; first start -> last end {s[:, :nw, nst - 1].max() - t0:.0f} ns")
 print("workgroup start spread %.0f ns" % (s[:, 0, 0].max() - t0))
-names = (["stage issue", "wait+barrier", "A1", "barrier", "B1", "barrier", "A2", "barrier", "B2+store"] if mode == "pair"
+names = (["stage issue", "wait+barrier", "A1", "barrier", "B1", "barrier", "A2", "barrier", "B2+store"] if mode in ("pair", "rs2")
          else ["stage issue", "wait+barrier", "A", "barrier", "B+store"])
 for k in range(nst - 1):
     d = s[:, :nw, k + 1] - s[:, :nw, k]
@@ -46,5 +52,8 @@ for k in range(nst - 1):
     per_wave = np.median(d, axis=0)
     print("%-14s median %6.0f  p10 %6.0f  p90 %6.0f   per-wave median: %s" % (names[k] if k < len(names) else k, np.median(act), np.percentile(act, 10),
           np.percentile(act, 90), " ".join("%4.0f" % v for v in per_wave)))
+dt = s[:, :nw, nst - 1] - s[:, :nw, 0]
+dc = cyc[:, :nw, nst - 1] - cyc[:, :nw, 0]
+print("shader clock over the kernel: median %.2f GHz" % np.median(dc / dt))
 tot = s[:, :nw, nst - 1].max(axis=1) - s[:, :nw, 0].min(axis=1)
 print("per-WG total median %.0f ns" % np.median(tot))
