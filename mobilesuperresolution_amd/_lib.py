@@ -9,8 +9,10 @@ from ctypes import c_int, c_size_t, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SR_HOTPATH_DEBUG_LIB=1 (tools/ only): the diagnostic build with in-kernel time stamps (build.py --debug)
-LIB_PATH = os.path.join(_HERE, "libsr_hotpath_dbg.so" if os.environ.get("SR_HOTPATH_DEBUG_LIB") == "1" else "libsr_hotpath.so")
+# SR_HOTPATH_DEBUG_LIB=1 (tools/ only): the diagnostic build with in-kernel time stamps (build.py --debug);
+# SR_HOTPATH_LIB_PATH (tools/ only): an explicitly named build of the same sources (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("SR_HOTPATH_LIB_PATH") or os.path.join(
+    _HERE, "libsr_hotpath_dbg.so" if os.environ.get("SR_HOTPATH_DEBUG_LIB") == "1" else "libsr_hotpath.so")
 ABI_VERSION = 3
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
 

@@ -24,6 +24,36 @@
 __device__ __attribute__((aligned(16))) const unsigned short g_sr_const_chunks[16] = {0x3F80, 0, 0, 0, 0, 0, 0, 0,
                                                                                       0,      0, 0, 0, 0, 0, 0, 0};
 
+// ---- LDS-DMA issued from inline asm: hipcc neither sees these operations nor waits for them, so the kernel can
+// leave the later phases' weights in flight across the first barrier and retire them with COUNTED s_waitcnt vmcnt(N)
+// (vmcnt retires in issue order; younger stores only make a counted wait conservative).  M0 (the LDS base of the
+// 64-lane piece) is written in the same statement that uses it. ----
+SR_DEV unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+SR_DEV void dma_piece16(const void* gsrc, unsigned lds_base) {     // 64 lanes x 16 B -> lds_base + lane * 16
+  unsigned keep;
+  const unsigned base = __builtin_amdgcn_readfirstlane(lds_base);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(base) : "memory");
+}
+SR_DEV void dma_piece4(const void* gsrc, unsigned lds_base) {      // 64 lanes x 4 B -> lds_base + lane * 4
+  unsigned keep;
+  const unsigned base = __builtin_amdgcn_readfirstlane(lds_base);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(base) : "memory");
+}
+template <int N> SR_DEV void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+// pieces [lo, hi) of a global piece list dealt round-robin to NW waves: how many does wave w issue?
+constexpr int pieces_of_wave(int lo, int hi, int w, int nw) {
+  int c = 0;
+  for (int p = lo; p < hi; ++p) c += (p % nw == w) ? 1 : 0;
+  return c;
+}
+
 template <int F_, int E_, int L_, int NBLK_> struct RsCfg {
   typedef BlockCfg<F_, E_, L_> C;
   static constexpr int NBLK = NBLK_, NWAVES = 8, NTHREADS = 64 * NWAVES;
@@ -42,35 +72,30 @@ template <int F_, int E_, int L_, int NBLK_> struct RsCfg {
   static constexpr int X1_ELEMS = NBLK > 1 ? npad(1) * KXL : 0;        // block 0's output = block 1's input
   static constexpr int ONES_ELEMS = 8;
   static constexpr int W_ELEMS = C::NFRAG_FWD * 512;
-  static constexpr int CL_FLOATS = (C::CINIT_FWD + 3) / 4 * 4;
+  static constexpr int CL_FLOATS = (C::CINIT_FWD + 63) / 64 * 64;      // whole 64-float DMA pieces per block
   static constexpr int LDS_BYTES = (X0_ELEMS + TT_ELEMS + X1_ELEMS + NBLK * W_ELEMS + ONES_ELEMS) * 2 + NBLK * CL_FLOATS * 4;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+  // staging piece list (one piece = one wave-instruction of LDS-DMA), dealt round-robin to the waves in this order:
+  // x region | C-init tables | block 0's weights || block 1's weights.  Only what precedes `||` is waited for
+  // before the first phase; the rest lands underneath it.
+  // x pieces: 21 pixels each (63 chunks) + the first chunk of the 22nd, which the next piece rewrites with the same
+  // bytes: every lane then owns a FIXED (pixel offset, chunk) pair and a piece costs one division by the row width
+  // (64 arbitrary chunks per piece cost two divisions and the staging loop was VALU-bound: 275 of a wave's 714 VALU ops)
+  static constexpr int PXP = 63 / C::FC, P_X = 0, NPX = (npad(0) + PXP - 1) / PXP;
+  static_assert(C::FC == 3, "piece geometry assumes 3 chunks per pixel");
+  static_assert(NPX * PXP * C::FC * 16 + 16 <= (X0_ELEMS + TT_ELEMS) * 2, "the last x piece may spill into the (not yet written) t image only");
+  static constexpr int P_C = P_X + NPX, NPC = NBLK * (CL_FLOATS / 64);
+  static constexpr int P_W = P_C + NPC, P_W1 = P_W + C::NFRAG_FWD, P_END = P_W + NBLK * C::NFRAG_FWD;
 };
-
-// stage rows [0, NROWS) of an LDS image [NROWS][F] by LDS-DMA: row p < NLIVE is pixel (y0 + p / RW, x0 + p % RW) of
-// the NHWC image `img`, zero outside the image (the lanes concerned read a 16-byte constant instead).
-template <typename C, int RW, int NLIVE, int NROWS, int NTHREADS>
-SR_DEV void stage_region_dma(__bf16* dst, const __bf16* __restrict__ img, int H, int W, int y0, int x0, int tid) {
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  constexpr int CH = C::FC, TOTAL = NROWS * CH, NW = NTHREADS / 64;
-  static_assert(TOTAL % 64 == 0, "whole 1 KiB pieces");
-  const int lane = tid & 63, wave = tid >> 6;
-  const char* zeros = reinterpret_cast<const char*>(g_sr_const_chunks) + 16;
-  for (int piece = wave; piece < TOTAL / 64; piece += NW) {
-    const int c = piece * 64 + lane;
-    const int p = c / CH, ch = c - p * CH;
-    const int py = p / RW, px = p - py * RW;
-    const int Y = y0 + py, X = x0 + px;
-    const char* src = zeros;
-    if (p < NLIVE && Y >= 0 && Y < H && X >= 0 && X < W) src = reinterpret_cast<const char*>(img + ((size_t)Y * W + X) * C::F + ch * 8);
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(reinterpret_cast<char*>(dst) + piece * 1024), 16, 0, 0);
-  }
-}
 
 // register-resident weights of one phase
 template <typename C> struct RwA {
+  static constexpr int N = C::NET * C::KS1 + C::KS2;
   bf16x8 w1[C::NET * C::KS1], w2[C::KS2];
+  SR_DEV void load_one(const __bf16* wl, int lane, int i) {            // i: compile-time after unrolling
+    if (i < C::NET * C::KS1) w1[i] = lds_chunk<__bf16>(wl, ((C::W1_OFF + i) * 64 + lane) * 8);
+    else if (i < N) w2[i - C::NET * C::KS1] = lds_chunk<__bf16>(wl, ((C::W2_OFF + i - C::NET * C::KS1) * 64 + lane) * 8);
+  }
   SR_DEV void load(const __bf16* wl, int lane) {
 #pragma unroll
     for (int i = 0; i < C::NET * C::KS1; ++i) w1[i] = lds_chunk<__bf16>(wl, ((C::W1_OFF + i) * 64 + lane) * 8);
@@ -79,7 +104,11 @@ template <typename C> struct RwA {
   }
 };
 template <typename C> struct RwB {
+  static constexpr int N = C::KS3;
   bf16x8 w3[C::KS3];
+  SR_DEV void load_one(const __bf16* wl, int lane, int i) {
+    if (i < N) w3[i] = lds_chunk<__bf16>(wl, ((C::W3_OFF + i) * 64 + lane) * 8);
+  }
   SR_DEV void load(const __bf16* wl, int lane) {
 #pragma unroll
     for (int i = 0; i < C::KS3; ++i) w3[i] = lds_chunk<__bf16>(wl, ((C::W3_OFF + i) * 64 + lane) * 8);
@@ -91,8 +120,8 @@ template <typename C> struct RwB {
 // i.e. four MFMAs with four VALU ops in each gap, every MFMA independent of the VALU ops right before it, and no
 // VALU op closer than two MFMAs behind the product it reads.  The conv2 accumulation order (a0, b0, a1, b1, ...)
 // is that of t_from_xb: bit-identical results.
-template <typename C>
-SR_DEV f32x16 rw_t_tile(const bf16x8 (&xb)[C::KS1], const RwA<C>& w, const float* cl, int hh) {
+template <typename C, int PFN = 0, typename PF>
+SR_DEV f32x16 rw_t_tile(const bf16x8 (&xb)[C::KS1], const RwA<C>& w, const float* cl, int hh, PF pf) {
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   // b2 and the ones channel of t, straight from the LDS table into the accumulator (4 broadcast reads; held in
   // registers it would cost 16 VGPRs and 16 copies per tile)
@@ -124,6 +153,7 @@ SR_DEV f32x16 rw_t_tile(const bf16x8 (&xb)[C::KS1], const RwA<C>& w, const float
   for (int et = 0; et < C::NET; ++et) {
     const bool more = et + 1 < C::NET;
     f32x16 hn = h;
+    pf(et);                                                                                     // PFN LDS reads for a later phase
     if (more) hn = conv1_step(conv1_init(et + 1), et + 1, 0);                                   // MFMA
     bf16x8 f0 = cvt4(h, 0);                                                                     // 4 VALU
     if (more) hn = conv1_step(hn, et + 1, 1);                                                   // MFMA
@@ -137,6 +167,7 @@ SR_DEV f32x16 rw_t_tile(const bf16x8 (&xb)[C::KS1], const RwA<C>& w, const float
     for (int k = 0; k < 4; ++k) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
       __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);    // 4 VALU
+      if (k < PFN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 LDS read (prefetch)
     }
   }
   if (2 * (C::NET - 1) + 1 < C::KS2) tacc = mma16<__bf16>(w.w2[2 * C::NET - 1], f1prev, tacc);
@@ -196,25 +227,38 @@ SR_DEV void rw_x_frags(bf16x8 (&xb)[C::KS1], const __bf16* Xin, const __bf16* on
 // phase A of one block over a region (RW wide, NP pixels, HALO around the tile): t -> TT.  Every wave takes tile
 // `wave` and, if there is one, tile `wave + NW`.  `prefetch()` is called once the wave's own operand reads are
 // issued: the next phase's weights travel LDS -> registers underneath this phase's MFMAs.
-template <typename C, int KXL, int RW, int NP, int HALO, int NW, bool SAVE_T, typename PF>
+template <typename C, int KXL, int RW, int NP, int HALO, int NW, bool SAVE_T, typename PF, typename BS>
 SR_DEV void rw_phase_a(const __bf16* Xin, const __bf16* ones, __bf16* TT, const RwA<C>& w, const float* cl, __bf16* tsave_tile,
-                       int H, int W, int ty0, int tx0, int wave, int lane, PF prefetch) {
+                       int H, int W, int ty0, int tx0, int wave, int lane, PF prefetch, BS before_stores) {
   constexpr int NT = (NP + 31) / 32;
   const int r = lane & 31, hh = lane >> 5;
   if (wave >= NT) {                                    // wave-uniform
-    prefetch();
+    prefetch(0, 64);
+    before_stores();
     return;
   }
   RwPix p = rw_pix_a<C, RW, NP, HALO>(wave * 32 + r, H, W, ty0, tx0);
   bf16x8 xb[C::KS1];
   rw_x_frags<C, KXL>(xb, Xin, ones, p.hp, hh);
-  prefetch();
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-  for (int tile = wave; tile < NT; tile += NW) {
-    const f32x16 t = rw_t_tile<C>(xb, w, cl, hh);
+  // first tile: the next phase's weights travel LDS -> registers in its MFMA gaps, PFN reads per e-tile (all at
+  // once they would queue ~500 LDS cycles in front of this phase's own operands)
+  constexpr int PFN = 4;
+  {
+    const f32x16 t = rw_t_tile<C, PFN>(xb, w, cl, hh, [&](int et) { prefetch(et * PFN, et * PFN + PFN); });
     const RwPix pc = p;
-    if (tile + NW < NT) {                              // the next tile's operands land while this one is converted and stored
+    if (wave + NW < NT) {                              // the next tile's operands land while this one is converted and stored
+      p = rw_pix_a<C, RW, NP, HALO>((wave + NW) * 32 + r, H, W, ty0, tx0);
+      rw_x_frags<C, KXL>(xb, Xin, ones, p.hp, hh);
+    }
+    prefetch(C::NET * PFN, 64);                        // (whatever is left)
+    before_stores();                                   // (counted-wait hook: no VMEM store of this wave has been issued yet)
+    rw_store_t<C, SAVE_T>(t, pc, TT, tsave_tile, hh);
+  }
+#pragma unroll 1
+  for (int tile = wave + NW; tile < NT; tile += NW) {
+    const f32x16 t = rw_t_tile<C>(xb, w, cl, hh, [](int) {});
+    const RwPix pc = p;
+    if (tile + NW < NT) {
       p = rw_pix_a<C, RW, NP, HALO>((tile + NW) * 32 + r, H, W, ty0, tx0);
       rw_x_frags<C, KXL>(xb, Xin, ones, p.hp, hh);
     }
@@ -283,17 +327,12 @@ struct RwPixB {
 template <typename C, int KXL, int RWO, int NPO, int HALOO>
 SR_DEV RwPixB rw_pix_b(int tile, int r, int H, int W, int ty0, int tx0) {
   RwPixB p;
-  int hp;
-  if constexpr (HALOO == 0) {                         // core: 4 x 8 pixel tiles (the layout the saved images use)
-    p.hy = (tile / (C::TW / 8)) * 4 + (r >> 3);
-    p.hx = (tile % (C::TW / 8)) * 8 + (r & 7);
-    hp = p.hy * RWO + p.hx;
-  } else {
-    hp = tile * 32 + r;
-    const int hpc = hp < NPO ? hp : 0;                // rows past the region: compute something finite, store it in the slack rows
-    p.hy = hpc / RWO;
-    p.hx = hpc - p.hy * RWO;
-  }
+  // 32 consecutive pixels of the row-major region per tile (also for the core: consecutive 48-byte t rows are a
+  // conflict-free stride for the 16-byte operand reads, 4 x 8 pixel patches were 2-3-way conflicted)
+  const int hp = tile * 32 + r;
+  const int hpc = hp < NPO ? hp : 0;                  // rows past the region: compute something finite, store it in the slack rows
+  p.hy = hpc / RWO;
+  p.hx = hpc - p.hy * RWO;
   p.xno = hp * KXL;
   const int Y = ty0 - HALOO + p.hy, X = tx0 - HALOO + p.hx;
   const bool st = hp < NPO && p.hy >= HALOO && p.hy < HALOO + C::TH && p.hx >= HALOO && p.hx < HALOO + C::TW && Y < H && X < W;
@@ -325,8 +364,8 @@ SR_DEV void rw_store_y(const f32x16& oacc, const RwPixB& p, __bf16* Xnext, __amd
 // One 3x3 chain: (MFMA, read) pairs in source order, pinned by sched_barrier: the pixel operand of k-step s + AHEAD is
 // requested right after the MFMA of k-step s (a 3x3 chain is one dependent accumulation, which issues back to back at
 // full rate).  `mid()` runs LAG MFMAs into the chain: the previous tile's stores go there.
-template <typename C, typename A, int AHEAD, int LAG, typename MID>
-SR_DEV f32x16 rw_b_chain(const A& a, const RwB<C>& w, MID mid) {
+template <typename C, typename A, int AHEAD, int LAG, typename MID, typename PF>
+SR_DEV f32x16 rw_b_chain(const A& a, const RwB<C>& w, MID mid, PF pf) {
   constexpr int KS3 = C::KS3;
   bf16x8 f[KS3];
 #pragma unroll
@@ -337,6 +376,7 @@ SR_DEV f32x16 rw_b_chain(const A& a, const RwB<C>& w, MID mid) {
   for (int s = 0; s < KS3; ++s) {
     acc = mma16<__bf16>(w.w3[s], f[s], acc);
     if (s + AHEAD < KS3) f[s + AHEAD] = a.frag(s + AHEAD);
+    pf(s);
     __builtin_amdgcn_sched_barrier(0);
     if (s == LAG) {
       mid();
@@ -354,7 +394,7 @@ SR_DEV void rw_phase_b(const __bf16* TT, const __bf16* Xin, __bf16* Xnext, __bf1
   static_assert(A::nsplit() <= 2, "two straddling k-steps at most");
   const int r = lane & 31, hh = lane >> 5;
   if (wave >= NT) {                                    // wave-uniform
-    prefetch();
+    prefetch(0, 64);
     return;
   }
   const bool to_global = yout != nullptr;
@@ -362,15 +402,16 @@ SR_DEV void rw_phase_b(const __bf16* TT, const __bf16* Xin, __bf16* Xnext, __bf1
   RwPixB p = rw_pix_b<C, KXL, RWO, NPO, HALOO>(wave, r, H, W, ty0, tx0);
   A a;
   a.init(TT, Xin, p.hy, p.hx, hh);
-  // first tile: nothing to store yet; the next phase's weights are requested behind its first reads
-  f32x16 acc = rw_b_chain<C, A, AHEAD, LAG>(a, w, [&] { prefetch(); });
+  // first tile: nothing to store yet; the next phase's weights travel LDS -> registers two reads per MFMA
+  f32x16 acc = rw_b_chain<C, A, AHEAD, LAG>(a, w, [] {}, [&](int s) { prefetch(2 * s, 2 * s + 2); });
+  prefetch(2 * C::KS3, 64);
 #pragma unroll 1
   for (int tile = wave + NW; tile < NT; tile += NW) {
     const RwPixB pp = p;
     const f32x16 pacc = acc;
     p = rw_pix_b<C, KXL, RWO, NPO, HALOO>(tile, r, H, W, ty0, tx0);
     a.init(TT, Xin, p.hy, p.hx, hh);
-    acc = rw_b_chain<C, A, AHEAD, LAG>(a, w, [&] { rw_store_y<C>(pacc, pp, Xnext, yrs, to_global, hh); });
+    acc = rw_b_chain<C, A, AHEAD, LAG>(a, w, [&] { rw_store_y<C>(pacc, pp, Xnext, yrs, to_global, hh); }, [](int) {});
   }
   rw_store_y<C>(acc, p, Xnext, yrs, to_global, hh);
 }
@@ -403,51 +444,80 @@ __global__ __launch_bounds__(512) void wdsr_fwd_rs_kernel(const __bf16* __restri
   SR_STAMP_DECL;
   SR_STAMP();
 
-  // ---- stage: x on the halo'd region, every weight fragment, the C-init tables ----
-  float civ = 0.f;                                                      // issued first, written to LDS last: one wait in all
-  if (tid < C::CINIT_FWD) civ = cia[tid];
-  if constexpr (NBLK > 1) {
-    if (tid >= 256 && tid < 256 + C::CINIT_FWD) civ = cib[tid - 256];
-  }
-  stage_region_dma<C, R::rw(0), R::np(0), R::npad(0), NTHREADS>(X0, x + img, H, W, ty0 - NBLK, tx0 - NBLK, tid);
-  stage_weights<__bf16, NTHREADS>(WL, wa, C::NFRAG_FWD, tid);
-  if constexpr (NBLK > 1) stage_weights<__bf16, NTHREADS>(WL + R::W_ELEMS, wb, C::NFRAG_FWD, tid);
+  // ---- stage (LDS-DMA from inline asm): x on the halo'd region, the C-init tables, block 0's weights.  A wave's
+  // DMA issue blocks once the CU's queue is full, i.e. issuing IS transferring (~55 GB/s per CU): block 1's weights
+  // are therefore issued only after the first barrier and land underneath phase A of block 0. ----
+  auto stage_pieces = [&](int lo, int hi) {
+    const char* zeros = reinterpret_cast<const char*>(g_sr_const_chunks) + 16;
+    const int y0 = ty0 - NBLK, x0 = tx0 - NBLK;
+    const int lq = lane / C::FC, lc = lane - lq * C::FC;      // this lane's fixed place in every x piece
+#pragma unroll 1
+    for (int p = lo + ((wave - lo) & (NW - 1)); p < hi; p += NW) {
+      if (p < R::P_C) {                                // x: 21 pixels x 3 chunks (+ 1 chunk of the next pixel) per piece
+        const int px_ = p * R::PXP + lq;
+        const int py = px_ / R::rw(0), pxx = px_ - py * R::rw(0);
+        const int Y = y0 + py, X = x0 + pxx;
+        const char* src = zeros;
+        if (px_ < R::np(0) && Y >= 0 && Y < H && X >= 0 && X < W)
+          src = reinterpret_cast<const char*>(x + img + ((size_t)Y * W + X) * C::F + lc * 8);
+        dma_piece16(src, lds_addr(X0) + p * (R::PXP * C::FC * 16));
+      } else if (p < R::P_W) {                         // C-init tables: 64 floats per piece, zeros past the table
+        const int k = p - R::P_C, blk = k / (R::CL_FLOATS / 64), i = (k % (R::CL_FLOATS / 64)) * 64 + lane;
+        const float* tab = (NBLK > 1 && blk == 1) ? cib : cia;
+        const char* src = i < C::CINIT_FWD ? reinterpret_cast<const char*>(tab + i) : zeros + (lane & 3) * 4;
+        dma_piece4(src, lds_addr(CL) + k * 256);
+      } else {                                         // weight fragments as they lie
+        const int fr = p - R::P_W;
+        const __bf16* wsrc = (NBLK > 1 && fr >= C::NFRAG_FWD) ? wb + (size_t)(fr - C::NFRAG_FWD) * 512 : wa + (size_t)fr * 512;
+        dma_piece16(reinterpret_cast<const char*>(wsrc + lane * 8), lds_addr(WL) + fr * 1024);
+      }
+    }
+  };
+  static_assert((NW & (NW - 1)) == 0, "power-of-two wave count");
+  stage_pieces(0, R::P_W1);
   if (tid < 8) ONES[tid] = tid == 0 ? (__bf16)1.f : (__bf16)0.f;
-  static_assert(C::CINIT_FWD <= 256, "one C-init float per thread");
-  if (tid < C::CINIT_FWD) CL[tid] = civ;
-  if constexpr (NBLK > 1) {
-    if (tid >= 256 && tid < 256 + C::CINIT_FWD) CL[R::CL_FLOATS + tid - 256] = civ;
-  }
   SR_STAMP();
+  wait_vmcnt<0>();                                      // each wave waits for its own pieces, the barrier joins them
   __syncthreads();
   SR_STAMP();
+  if constexpr (NBLK > 1) stage_pieces(R::P_W1, R::P_END);
 
   __bf16* const tsa_tile = SAVE_T ? tsa + tile_g * (C::TH * C::TW) * C::LP : nullptr;
   __bf16* const tsb_tile = (SAVE_T && NBLK > 1) ? tsb + tile_g * (C::TH * C::TW) * C::LP : nullptr;
   RwA<C> rwa;
   RwB<C> rwb;
   rwa.load(WL, lane);
+  auto pf_a = [&](const __bf16* wl, int lo, int hi) {   // fragments [lo, hi) of the next conv1 / conv2 weights
+#pragma unroll
+    for (int i = 0; i < RwA<C>::N; ++i)
+      if (i >= lo && i < hi) rwa.load_one(wl, lane, i);
+  };
+  auto pf_b = [&](const __bf16* wl, int lo, int hi) {
+#pragma unroll
+    for (int i = 0; i < RwB<C>::N; ++i)
+      if (i >= lo && i < hi) rwb.load_one(wl, lane, i);
+  };
   // ---- block 0 ----
   rw_phase_a<C, KXL, R::rw(0), R::np(0), NBLK, NW, SAVE_T>(X0, ONES, TT, rwa, CL, tsa_tile, H, W, ty0, tx0, wave, lane,
-                                                             [&] { rwb.load(WL, lane); });
+                                                             [&](int lo, int hi) { pf_b(WL, lo, hi); }, [] { wait_vmcnt<0>(); });
   SR_STAMP();
   __syncthreads();
   SR_STAMP();
   if constexpr (NBLK == 1) {
-    rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NW>(TT, X0, nullptr, yb + img, rwb, H, W, ty0, tx0, wave, lane, [] {});
+    rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NW>(TT, X0, nullptr, yb + img, rwb, H, W, ty0, tx0, wave, lane, [](int, int) {});
   } else {
     rw_phase_b<C, KXL, R::rw(1), R::np(1), NBLK - 1, NW>(TT, X0, X1, ya ? ya + img : nullptr, rwb, H, W, ty0, tx0, wave, lane,
-                                                         [&] { rwa.load(WL + R::W_ELEMS, lane); });
+                                                         [&](int lo, int hi) { pf_a(WL + R::W_ELEMS, lo, hi); });
     SR_STAMP();
     __syncthreads();
     SR_STAMP();
     // ---- block 1 ----
     rw_phase_a<C, KXL, R::rw(1), R::np(1), NBLK - 1, NW, SAVE_T>(X1, ONES, TT, rwa, CL + R::CL_FLOATS, tsb_tile, H, W, ty0, tx0, wave,
-                                                                 lane, [&] { rwb.load(WL + R::W_ELEMS, lane); });
+                                                                 lane, [&](int lo, int hi) { pf_b(WL + R::W_ELEMS, lo, hi); }, [] {});
     SR_STAMP();
     __syncthreads();
     SR_STAMP();
-    rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NW>(TT, X1, nullptr, yb + img, rwb, H, W, ty0, tx0, wave, lane, [] {});
+    rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NW>(TT, X1, nullptr, yb + img, rwb, H, W, ty0, tx0, wave, lane, [](int, int) {});
   }
   SR_STAMP();
 }

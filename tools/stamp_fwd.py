@@ -50,7 +50,9 @@ for k in range(nst - 1):
     d = s[:, :nw, k + 1] - s[:, :nw, k]
     act = d[d < 1e6]
     per_wave = np.median(d, axis=0)
-    print("%-14s median %6.0f  p10 %6.0f  p90 %6.0f   per-wave median: %s" % (names[k] if k < len(names) else k, np.median(act), np.percentile(act, 10),
+    dcy = cyc[:, :nw, k + 1] - cyc[:, :nw, k]
+    print("%-14s median %6.0f ns = %6.0f cycles (%.2f GHz)  p10 %6.0f  p90 %6.0f   per-wave median ns: %s" % (
+          names[k] if k < len(names) else k, np.median(act), np.median(dcy), np.median(dcy) / max(np.median(act), 1), np.percentile(act, 10),
           np.percentile(act, 90), " ".join("%4.0f" % v for v in per_wave)))
 dt = s[:, :nw, nst - 1] - s[:, :nw, 0]
 dc = cyc[:, :nw, nst - 1] - cyc[:, :nw, 0]

@@ -31,9 +31,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k(const __bf16* w, const __bf16* x
   __bf16* yout = out + (size_t)blockIdx.x * 48 * 48 * 24;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it) {
-    rw_phase_a<C, R::KXL, R::rw(0), R::np(0), 1, NW, false>(X0, ONES, TT, rwa, CL, nullptr, 48, 48, 12, 24, wave, lane, [] {});
+    rw_phase_a<C, R::KXL, R::rw(0), R::np(0), 1, NW, false>(X0, ONES, TT, rwa, CL, nullptr, 48, 48, 12, 24, wave, lane, [](int, int) {}, [] {});
     __syncthreads();
-    rw_phase_b<C, R::KXL, C::TW, C::TH * C::TW, 0, NW>(TT, X0, nullptr, yout, rwb, 48, 48, 12, 24, wave, lane, [] {});
+    rw_phase_b<C, R::KXL, C::TW, C::TH * C::TW, 0, NW>(TT, X0, nullptr, yout, rwb, 48, 48, 12, 24, wave, lane, [](int, int) {});
     __syncthreads();
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
