@@ -8,7 +8,11 @@ A "step" is one pass of the hot path over one batch of synthetic 48x48 LR patche
 in HBM: forward (head, 16 fused residual blocks, fused tail+skip+PixelShuffle), L1 loss, backward,
 Adam step -- what pretrain.py's train() does per batch (reference pretrain.py:61-80).  Workload at
 every N: BASELINE.json configs[1] (x4, 16 blocks / 24 units, bf16 storage, batch 32 per GPU, weak
-scaling); for N > 1 the model is wrapped in DistributedDataParallel over RCCL as pretrain.py:239 does.
+scaling).  N = 1 times `model.train_step` (loss folded into the tail backward, Adam kernel, one C call);
+for N > 1 the model is wrapped in DistributedDataParallel over RCCL as pretrain.py:239 does and the step
+is forward / F.l1_loss / backward (bucketed all-reduce) / Adam.  The line also carries the same step through
+the plain nn.Module route (`unfused_ms_per_step`) and with the per-step `loss.item()` of pretrain.py:82
+(`ms_per_step_with_item_sync`), and the per-step distribution (median, p10, p90 from HIP events).
 
 Rank 0 prints ONE JSON line (metric, value, ..., roofline, cpu_baseline).
 """
@@ -108,8 +112,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus} (one rank per GPU)")
     if os.environ.get("SR_BENCH_SHARED_GPU") == "1":    # rehearsal of the N > 1 control flow on a one-GPU box (with gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -140,13 +144,19 @@ def main():
     x = torch.rand(BATCH, 3, LR, LR, generator=g).to(dev)
     hr = torch.rand(BATCH, 3, LR * SCALE, LR * SCALE, generator=g).to(dev)
 
-    def step():
+    def step_unfused():
         opt.zero_grad(set_to_none=True)
         sr = net(x)
         loss = torch.nn.functional.l1_loss(sr, hr)
         loss.backward()
         opt.step()
         return loss
+
+    fused = not use_ddp                                  # one rank: the whole step is one call into the library
+    state = model.make_train_state(lr=lr_rate) if fused else None
+
+    def step():
+        return model.train_step(x, hr, state) if fused else step_unfused()
 
     def sync():
         if use_ddp:
@@ -166,6 +176,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = float(loss.detach())
+
+    # the same step, untimed for `value`: per-step distribution (HIP events on the launch stream, no host sync inside the
+    # loop), with the per-step loss.item() sync of pretrain.py:82, and through the plain nn.Module / torch.optim route
+    def per_step_ms(fn, n):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        ev[0].record()
+        for i in range(n):
+            fn()
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n))
+
+    def wall_ms(fn, n):
+        sync()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        sync()
+        return (time.perf_counter() - t) / n * 1e3
+    nd = max(args.steps, 50)
+    dist_ms = per_step_ms(step, nd)
+    item_ms = wall_ms(lambda: step().item(), nd)
+    unfused_ms = None
+    if fused:
+        for _ in range(5):                               # (torch's optimizer initialises its state on first use)
+            step_unfused()
+        unfused_ms = wall_ms(step_unfused, nd)
 
     # forward-only (inference) throughput, same batch
     model.eval()
@@ -187,7 +224,7 @@ def main():
     if rank == 0:
         L.set_timer(timer)
     for _ in range(5):
-        step()
+        step_unfused()
     L.set_timer(None)
     sync()
 
@@ -250,6 +287,12 @@ def main():
             "value": round(world * BATCH * HR_MPIX_PER_PATCH * args.steps / elapsed, 2),
             "unit": "HR-Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "step_route": "model.train_step: loss folded into the tail backward + Adam kernel, one C call" if fused
+                          else "DistributedDataParallel: forward / F.l1_loss / backward + all-reduce / torch Adam",
+            "per_step_ms": {"n": nd, "median": round(dist_ms[nd // 2], 4), "p10": round(dist_ms[nd // 10], 4),
+                            "p90": round(dist_ms[(nd * 9) // 10], 4)},
+            "ms_per_step_with_item_sync": round(item_ms, 4),
+            "unfused_ms_per_step": None if unfused_ms is None else round(unfused_ms, 4),
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"WDSR-B x{SCALE}, {BLOCKS} blocks / {UNITS} units, {LR}x{LR} LR patches, "
                                    f"batch {BATCH} per GPU, fwd+L1+bwd+Adam" + (f", DDP/{'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()}" if use_ddp else ""),

@@ -222,6 +222,10 @@ typedef struct {
   const float* x; void* acts; void* grads; float* out; const float* dout;
   /* optional (bf16; NULL = recompute in backward): t and dt of every block, [NB][N][tiles][288][LP] */
   void* tsave; void* dtsave;
+  /* optional loss fold (hr != NULL): backward reads `out` and `hr` (NCHW fp32 HR target) instead of `dout` and forms
+   * the L1 (loss_kind 1, pretrain.py:73) or Charbonnier (2, train_video_superresolution.py:43-53) gradient on the
+   * fly, loss_gscale = upstream gradient / numel; loss_part[wgs_tail] receives the per-workgroup loss sums */
+  const float* hr; int loss_kind; float loss_gscale; float* loss_part;
 } sr_wdsr_net_t;
 
 /* weight-norm + packing + head + NB fused blocks + fused tail.  flags: SR_NET_SAVE_ACTS keeps every block input
@@ -230,9 +234,28 @@ typedef struct {
  * inference with unchanged parameters). */
 #define SR_NET_SAVE_ACTS 1
 #define SR_NET_WEIGHTS_PACKED 2
+#define SR_NET_PACK_ONLY 4   /* weight-norm + packing of `flat` into the blobs, nothing else (backward after the blobs were re-packed) */
 int sr_wdsr_net_forward(const sr_wdsr_net_t* net, int flags, sr_stream_t stream);
 /* full backward: d(loss)/d(out) -> gflat (gradient of every parameter in the flat buffer). */
 int sr_wdsr_net_backward(const sr_wdsr_net_t* net, sr_stream_t stream);
+
+/* Tail backward with the loss folded in (see sr_wdsr_net_t.hr): sr = network output, hr = target. */
+int sr_tail_bwd_loss(const float* sr, const float* hr, int loss_kind, float gscale, float* loss_part, const void* feat,
+                     const float* x_nchw, float mean, const void* wblob, void* dfeat, float* partial, int wgs, int N, int H,
+                     int W, int F, int R, int dtype, sr_stream_t stream);
+
+/* One Adam step over a flat fp32 parameter buffer with the arithmetic of torch.optim.Adam's default (foreach)
+ * implementation (pretrain.py:137: lr 1e-3 x world, betas (0.9, 0.999), eps 1e-8, no weight decay).  The caller
+ * computes the step-dependent scalars in double and rounds them to float, as torch does:
+ *   w_lerp = 1 - beta1, one_minus_beta2 = 1 - beta2, bc2_sqrt = sqrt(1 - beta2^t), neg_step_size = -lr / (1 - beta1^t).
+ * loss_out (may be NULL) = loss_scale * sum(loss_part[0 .. n_loss)). */
+typedef struct { float w_lerp, beta2, one_minus_beta2, bc2_sqrt, eps, neg_step_size; } sr_adam_t;
+int sr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, const sr_adam_t* a,
+                 const float* loss_part, int n_loss, float loss_scale, float* loss_out, sr_stream_t stream);
+int sr_loss_value(const float* loss_part, int n_loss, float loss_scale, float* loss_out, sr_stream_t stream);
+/* forward + loss-folded backward + Adam in one call (net->hr etc. set; net->flat is updated in place). */
+int sr_wdsr_net_train_step(const sr_wdsr_net_t* net, float* exp_avg, float* exp_avg_sq, long n_params, const sr_adam_t* a,
+                           float loss_scale, float* loss_out, sr_stream_t stream);
 
 /* ---- hardware probes used by tests/test_gpu_probe.py (lane maps the kernels rely on) ---- */
 int sr_probe_mfma_bf16(const void* a_frag, const void* b_frag, float* acc_out, sr_stream_t stream);

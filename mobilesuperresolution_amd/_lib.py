@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SR_HOTPATH_LIB_PATH (tools/ only): an explicitly named build of the same sources (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("SR_HOTPATH_LIB_PATH") or os.path.join(
     _HERE, "libsr_hotpath_dbg.so" if os.environ.get("SR_HOTPATH_DEBUG_LIB") == "1" else "libsr_hotpath.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
 
 _P, _I, _Z, _L, _F = c_void_p, c_int, c_size_t, ctypes.c_long, ctypes.c_float
@@ -52,6 +52,10 @@ SIGNATURES = {
     "sr_nas_pw_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "sr_nas_pw_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_nas_dw_bwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
+    "sr_tail_bwd_loss": ([_P, _P, _I, _F, _P, _P, _P, _F, _P, _P, _P] + [_I] * 7 + [_P], _I),
+    "sr_adam_step": ([_P, _P, _P, _P, _L, _P, _P, _I, _F, _P, _P], _I),
+    "sr_loss_value": ([_P, _I, _F, _P, _P], _I),
+    "sr_wdsr_net_train_step": ([_P, _P, _P, _L, _P, _F, _P, _P], _I),
     "sr_wdsr_net_forward": ([_P, _I, _P], _I),
     "sr_wdsr_net_backward": ([_P, _P], _I),
     "sr_probe_mfma_bf16": ([_P, _P, _P, _P], _I),
@@ -74,7 +78,13 @@ class WdsrNet(ctypes.Structure):
         [(n, _I) for n in ("wgs_body", "wgs_tail", "wgs_head", "slab_a", "slab_b", "slab_tail", "slab_head")] +
         [("ga_sidx", _P), ("ga_dst", _P), ("n_ga", _I), ("gb_sidx", _P), ("gb_dst", _P), ("n_gb", _I),
          ("gt_sidx", _P), ("gt_dst", _P), ("n_gt", _I), ("gh_sidx", _P), ("gh_dst", _P), ("n_gh", _I),
-         ("x", _P), ("acts", _P), ("grads", _P), ("out", _P), ("dout", _P), ("tsave", _P), ("dtsave", _P)])
+         ("x", _P), ("acts", _P), ("grads", _P), ("out", _P), ("dout", _P), ("tsave", _P), ("dtsave", _P),
+         ("hr", _P), ("loss_kind", _I), ("loss_gscale", _F), ("loss_part", _P)])
+
+
+class AdamScalars(ctypes.Structure):
+    """mirror of sr_adam_t"""
+    _fields_ = [(n, _F) for n in ("w_lerp", "beta2", "one_minus_beta2", "bc2_sqrt", "eps", "neg_step_size")]
 
 
 _lib = None
@@ -107,8 +117,9 @@ def lib():
     return _lib
 
 
-def stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def stream_ptr(device=None) -> int:
+    """the current HIP stream of `device` (default: the current device)"""
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def check(rc: int, what: str):

@@ -9,8 +9,9 @@
 #include "conv3x3.h"
 #include "nas_block.h"
 #include "flow_warp.h"
+#include "train_step.h"
 
-extern "C" int sr_abi_version(void) { return 3; }
+extern "C" int sr_abi_version(void) { return 4; }
 
 namespace {
 
@@ -261,12 +262,15 @@ extern "C" int sr_tail_fwd(const void* feat, const float* x, float* out, const v
   return 0;
 }
 
-extern "C" int sr_tail_bwd_data(const float* dout, void* dfeat, const void* wblob, int N, int H, int W, int F,
-                                int R, int dtype, sr_stream_t stream) {
-  if (!dout || !dfeat || !wblob || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
-  hipStream_t st = (hipStream_t)stream;
+namespace {
+// LOSS = 0: `dout` is d(loss)/d(out).  LOSS = 1 (L1) / 2 (Charbonnier): `dout` is the network output, `hr` the target,
+// gscale = upstream gradient / numel; the wgrad / fused kernels also write one loss partial sum per workgroup.
+template <int LOSS>
+int tail_bwd_data_t(const float* dout, const float* hr, float gscale, void* dfeat, const void* wblob, int N, int H, int W, int F,
+                    int R, int dtype, hipStream_t st) {
+  const LossIn li{hr, gscale};
 #define CALLR(T, F_, R_) { typedef EndsCfg<F_, R_> E; int tx; dim3 g = tile_grid<E>(N, H, W, &tx); \
-    hipLaunchKernelGGL((sr_tail_bwd_data_kernel<T, F_, R_>), g, dim3(256), 0, st, dout, (T*)dfeat, (const T*)wblob, H, W, tx); }
+    hipLaunchKernelGGL((sr_tail_bwd_data_kernel<T, F_, R_, LOSS>), g, dim3(256), 0, st, dout, (T*)dfeat, (const T*)wblob, H, W, tx, li); }
 #define CALL(T, F_) SR_DISPATCH_R(CALLR, T, F_)
   SR_DISPATCH_TF(CALL)
 #undef CALL
@@ -274,19 +278,43 @@ extern "C" int sr_tail_bwd_data(const float* dout, void* dfeat, const void* wblo
   SR_HIP_CHECK_LAUNCH();
   return 0;
 }
-
-extern "C" int sr_tail_wgrad(const float* dout, const void* feat, const float* x, float mean, float* partial,
-                             int wgs, int N, int H, int W, int F, int R, int dtype, sr_stream_t stream) {
-  if (!dout || !feat || !x || !partial || wgs <= 0 || N <= 0 || H <= 0 || W <= 0) return -2;
-  hipStream_t st = (hipStream_t)stream;
+template <int LOSS>
+int tail_wgrad_t(const float* dout, const float* hr, float gscale, float* loss_part, const void* feat, const float* x, float mean,
+                 float* partial, int wgs, int N, int H, int W, int F, int R, int dtype, hipStream_t st) {
+  const LossIn li{hr, gscale};
 #define CALLR(T, F_, R_) { typedef EndsCfg<F_, R_> E; const int tx = (W + E::TW - 1) / E::TW, tpi = tx * ((H + E::TH - 1) / E::TH); \
-    hipLaunchKernelGGL((sr_tail_wgrad_kernel<T, F_, R_>), dim3(wgs), dim3(896), 0, st, dout, (const T*)feat, x, mean, partial, N, H, W, tx, tpi); }
+    hipLaunchKernelGGL((sr_tail_wgrad_kernel<T, F_, R_, LOSS>), dim3(wgs), dim3(896), 0, st, dout, (const T*)feat, x, mean, partial, N, H, W, tx, tpi, li, loss_part); }
 #define CALL(T, F_) SR_DISPATCH_R(CALLR, T, F_)
   SR_DISPATCH_TF(CALL)
 #undef CALL
 #undef CALLR
   SR_HIP_CHECK_LAUNCH();
   return 0;
+}
+template <int LOSS>
+int tail_bwd_t(const float* dout, const float* hr, float gscale, float* loss_part, const void* feat, const float* x, float mean,
+               const void* wblob, void* dfeat, float* partial, int wgs, int N, int H, int W, int F, int R, hipStream_t st) {
+  const LossIn li{hr, gscale};
+  typedef __bf16 TB;
+#define CALLR(T, F_, R_) { typedef EndsCfg<F_, R_> E; const int tx = (W + E::TW - 1) / E::TW, tpi = tx * ((H + E::TH - 1) / E::TH); \
+    hipLaunchKernelGGL((sr_tail_bwd_kernel<T, F_, R_, LOSS>), dim3(wgs), dim3(896), 0, st, dout, (const T*)feat, x, mean, (const T*)wblob, (T*)dfeat, partial, N, H, W, tx, tpi, li, loss_part); }
+  if (F == 24) { SR_DISPATCH_R(CALLR, TB, 24) } else if (F == 32) { SR_DISPATCH_R(CALLR, TB, 32) } else return -1;
+#undef CALLR
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+}  // namespace
+
+extern "C" int sr_tail_bwd_data(const float* dout, void* dfeat, const void* wblob, int N, int H, int W, int F,
+                                int R, int dtype, sr_stream_t stream) {
+  if (!dout || !dfeat || !wblob || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
+  return tail_bwd_data_t<0>(dout, nullptr, 0.f, dfeat, wblob, N, H, W, F, R, dtype, (hipStream_t)stream);
+}
+
+extern "C" int sr_tail_wgrad(const float* dout, const void* feat, const float* x, float mean, float* partial,
+                             int wgs, int N, int H, int W, int F, int R, int dtype, sr_stream_t stream) {
+  if (!dout || !feat || !x || !partial || wgs <= 0 || N <= 0 || H <= 0 || W <= 0) return -2;
+  return tail_wgrad_t<0>(dout, nullptr, 0.f, nullptr, feat, x, mean, partial, wgs, N, H, W, F, R, dtype, (hipStream_t)stream);
 }
 
 extern "C" int sr_tail_bwd(const float* dout, const void* feat, const float* x, float mean, const void* wblob,
@@ -294,14 +322,26 @@ extern "C" int sr_tail_bwd(const float* dout, const void* feat, const float* x, 
                           sr_stream_t stream) {
   if (!dout || !feat || !x || !wblob || !dfeat || !partial || wgs <= 0 || N <= 0 || H <= 0 || W <= 0) return -2;
   if (dtype != SR_DTYPE_BF16) return -1;
+  return tail_bwd_t<0>(dout, nullptr, 0.f, nullptr, feat, x, mean, wblob, dfeat, partial, wgs, N, H, W, F, R, (hipStream_t)stream);
+}
+
+// tail backward with the loss folded in: `sr` = network output, `hr` = target (both NCHW fp32 HR), loss_kind 1 = L1,
+// 2 = Charbonnier; writes dfeat, the weight-gradient slabs and loss_part[wgs] (sums of |sr - hr| resp. sqrt(d^2 + eps))
+extern "C" int sr_tail_bwd_loss(const float* sr, const float* hr, int loss_kind, float gscale, float* loss_part, const void* feat,
+                                const float* x, float mean, const void* wblob, void* dfeat, float* partial, int wgs, int N,
+                                int H, int W, int F, int R, int dtype, sr_stream_t stream) {
+  if (!sr || !hr || !loss_part || !feat || !x || !wblob || !dfeat || !partial || wgs <= 0 || N <= 0 || H <= 0 || W <= 0 || N > 65535)
+    return -2;
+  if (loss_kind != 1 && loss_kind != 2) return -1;
   hipStream_t st = (hipStream_t)stream;
-  typedef __bf16 TB;
-#define CALLR(T, F_, R_) { typedef EndsCfg<F_, R_> E; const int tx = (W + E::TW - 1) / E::TW, tpi = tx * ((H + E::TH - 1) / E::TH); \
-    hipLaunchKernelGGL((sr_tail_bwd_kernel<T, F_, R_>), dim3(wgs), dim3(896), 0, st, dout, (const T*)feat, x, mean, (const T*)wblob, (T*)dfeat, partial, N, H, W, tx, tpi); }
-  if (F == 24) { SR_DISPATCH_R(CALLR, TB, 24) } else if (F == 32) { SR_DISPATCH_R(CALLR, TB, 32) } else return -1;
-#undef CALLR
-  SR_HIP_CHECK_LAUNCH();
-  return 0;
+  if (dtype == SR_DTYPE_BF16)
+    return loss_kind == 1 ? tail_bwd_t<1>(sr, hr, gscale, loss_part, feat, x, mean, wblob, dfeat, partial, wgs, N, H, W, F, R, st)
+                          : tail_bwd_t<2>(sr, hr, gscale, loss_part, feat, x, mean, wblob, dfeat, partial, wgs, N, H, W, F, R, st);
+  int rc = loss_kind == 1 ? tail_bwd_data_t<1>(sr, hr, gscale, dfeat, wblob, N, H, W, F, R, dtype, st)
+                          : tail_bwd_data_t<2>(sr, hr, gscale, dfeat, wblob, N, H, W, F, R, dtype, st);
+  if (rc) return rc;
+  return loss_kind == 1 ? tail_wgrad_t<1>(sr, hr, gscale, loss_part, feat, x, mean, partial, wgs, N, H, W, F, R, dtype, st)
+                        : tail_wgrad_t<2>(sr, hr, gscale, loss_part, feat, x, mean, partial, wgs, N, H, W, F, R, dtype, st);
 }
 
 extern "C" int sr_head_wgrad(const void* dy0, const float* x, float mean, float* partial, int wgs, int N, int H,
@@ -603,13 +643,14 @@ static size_t side_image_bytes(const sr_wdsr_net_t* n) {     // one block's [N][
 }
 
 extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int flags, sr_stream_t stream) {
-  if (!n || !n->flat || !n->src || !n->x || !n->acts || !n->out) return -2;
+  if (!n || !n->flat || !n->src) return -2;
+  if (!(flags & SR_NET_PACK_ONLY) && (!n->x || !n->acts || !n->out)) return -2;
   hipStream_t st = (hipStream_t)stream;
   const size_t esz = n->dtype == SR_DTYPE_BF16 ? 2 : 4;
   const int save_acts = flags & SR_NET_SAVE_ACTS;
   int rc = 0;
   if (!(flags & SR_NET_WEIGHTS_PACKED)) rc = n->dtype == SR_DTYPE_BF16 ? net_pack<__bf16>(n, st) : net_pack<float>(n, st);
-  if (rc) return rc;
+  if (rc || (flags & SR_NET_PACK_ONLY)) return rc;
   const size_t act = (size_t)n->N * n->H * n->W * n->F * esz;
   const size_t blob = (size_t)n->n_idx_body * esz;
   char* acts = (char*)n->acts;
@@ -658,7 +699,8 @@ extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int flags, sr_stream_
 }
 
 extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) {
-  if (!n || !n->flat || !n->gflat || !n->dsrc || !n->x || !n->acts || !n->grads || !n->dout) return -2;
+  if (!n || !n->flat || !n->gflat || !n->dsrc || !n->x || !n->acts || !n->grads) return -2;
+  if (n->hr ? (!n->out || !n->loss_part || (n->loss_kind != 1 && n->loss_kind != 2)) : !n->dout) return -2;
   hipStream_t st = (hipStream_t)stream;
   const size_t esz = n->dtype == SR_DTYPE_BF16 ? 2 : 4;
   const size_t act = (size_t)n->N * n->H * n->W * n->F * esz;
@@ -667,7 +709,12 @@ extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) 
   char* acts = (char*)n->acts;
   char* grads = (char*)n->grads;
   int rc;
-  if (n->dtype == SR_DTYPE_BF16) {                  // data + weight gradients of the tail in one launch
+  if (n->hr) {                                      // loss folded into the tail backward: no HR gradient tensor
+    if ((rc = sr_tail_bwd_loss(n->out, n->hr, n->loss_kind, n->loss_gscale, n->loss_part, acts + (size_t)n->NB * act, n->x, n->mean,
+                               n->blob_tail, grads + (size_t)n->NB * act, n->part_tail, n->wgs_tail, n->N, n->H, n->W, n->F, n->R,
+                               n->dtype, stream)))
+      return rc;
+  } else if (n->dtype == SR_DTYPE_BF16) {           // data + weight gradients of the tail in one launch
     if ((rc = sr_tail_bwd(n->dout, acts + (size_t)n->NB * act, n->x, n->mean, n->blob_tail, grads + (size_t)n->NB * act,
                           n->part_tail, n->wgs_tail, n->N, n->H, n->W, n->F, n->R, n->dtype, stream)))
       return rc;
@@ -744,6 +791,36 @@ extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) 
                      (const int4*)n->chan_tab, n->n_chan, n->bias_tab, n->n_bias, cb);
   SR_HIP_CHECK_LAUNCH();
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// loss / optimizer epilogue
+// ------------------------------------------------------------------------------------------
+extern "C" int sr_adam_step(float* p, const float* g, float* m, float* v, long n, const sr_adam_t* a, const float* loss_part,
+                            int n_loss, float loss_scale, float* loss_out, sr_stream_t stream) {
+  if (!p || !g || !m || !v || !a || n <= 0 || (loss_out && (!loss_part || n_loss <= 0))) return -2;
+  const AdamArgs aa{a->w_lerp, a->beta2, a->one_minus_beta2, a->bc2_sqrt, a->eps, a->neg_step_size};
+  const long blocks = (n + 1023) / 1024;
+  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, aa, loss_part, n_loss,
+                     loss_scale, loss_out);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int sr_loss_value(const float* loss_part, int n_loss, float loss_scale, float* loss_out, sr_stream_t stream) {
+  if (!loss_part || !loss_out || n_loss <= 0) return -2;
+  hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_part, n_loss, loss_scale, loss_out);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+// forward + loss-folded backward + Adam from ONE call: net->hr / loss_kind / loss_gscale / loss_part set by the caller;
+// `flat` is updated in place, *loss_out = loss_scale * sum(loss partials)
+extern "C" int sr_wdsr_net_train_step(const sr_wdsr_net_t* n, float* m, float* v, long n_params, const sr_adam_t* a,
+                                      float loss_scale, float* loss_out, sr_stream_t stream) {
+  if (!n || !n->hr || !m || !v || !a || n_params <= 0) return -2;
+  int rc;
+  if ((rc = sr_wdsr_net_forward(n, SR_NET_SAVE_ACTS, stream))) return rc;
+  if ((rc = sr_wdsr_net_backward(n, stream))) return rc;
+  return sr_adam_step(const_cast<float*>(n->flat), n->gflat, m, v, n_params, a, n->loss_part, n->wgs_tail, loss_scale, loss_out, stream);
 }
 
 // ------------------------------------------------------------------------------------------

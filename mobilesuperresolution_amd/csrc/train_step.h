@@ -1,0 +1,66 @@
+// Loss / optimizer epilogue of the training step.  Reference: pretrain.py:73-80 (L1 loss, backward,
+// Adam step; Adam hyper-parameters pretrain.py:137) and train_video_superresolution.py:43-53 (Charbonnier).
+#pragma once
+#include "sr_common.h"
+
+// One Adam step over the flat parameter buffer with the arithmetic of torch.optim.Adam's default (foreach)
+// implementation, op for op and rounding for rounding (tests/test_gpu_train_step.py checks bit equality):
+//   m = lerp(m, g, 1 - beta1)                        torch._foreach_lerp_   : m + w (g - m), fused multiply-add
+//   v = v * beta2;  v = v + (1 - beta2) * (g * g)    _foreach_mul_, _foreach_addcmul_
+//   d = sqrt(v) / sqrt(1 - beta2^t) + eps            _foreach_sqrt, _foreach_div_, _foreach_add_
+//   p = p + (-lr / (1 - beta1^t)) * (m / d)          _foreach_addcdiv_
+// The step-dependent scalars are computed by the caller in double and rounded to float, as torch does when it
+// hands Python floats to its kernels.  Block 0 also folds the tail kernel's per-workgroup loss partial sums
+// into the loss value (mean over the HR tensor times the loss weight), so reading the loss costs no launch.
+struct AdamArgs {
+  float w_lerp, beta2, one_minus_beta2, bc2_sqrt, eps, neg_step_size;
+};
+__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, long n, AdamArgs a,
+                                                        const float* __restrict__ loss_part, int n_loss, float loss_scale,
+                                                        float* __restrict__ loss_out) {
+  const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 + 3 < n) {
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i0);
+    f32x4 mv = *reinterpret_cast<const f32x4*>(m + i0), vv = *reinterpret_cast<const f32x4*>(v + i0);
+    f32x4 pv = *reinterpret_cast<const f32x4*>(p + i0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mv[j] = __builtin_fmaf(a.w_lerp, gv[j] - mv[j], mv[j]);
+      const float vb = vv[j] * a.beta2;
+      vv[j] = __builtin_fmaf(a.one_minus_beta2, gv[j] * gv[j], vb);
+      const float d = __builtin_sqrtf(vv[j]) / a.bc2_sqrt + a.eps;
+      pv[j] = __builtin_fmaf(a.neg_step_size, mv[j] / d, pv[j]);
+    }
+    *reinterpret_cast<f32x4*>(m + i0) = mv;
+    *reinterpret_cast<f32x4*>(v + i0) = vv;
+    *reinterpret_cast<f32x4*>(p + i0) = pv;
+  } else {
+    for (long i = i0; i < n; ++i) {
+      const float gi = g[i];
+      const float mi = __builtin_fmaf(a.w_lerp, gi - m[i], m[i]);
+      const float vi = __builtin_fmaf(a.one_minus_beta2, gi * gi, v[i] * a.beta2);
+      const float d = __builtin_sqrtf(vi) / a.bc2_sqrt + a.eps;
+      m[i] = mi;
+      v[i] = vi;
+      p[i] = __builtin_fmaf(a.neg_step_size, mi / d, p[i]);
+    }
+  }
+  if (loss_out && blockIdx.x == 0 && threadIdx.x < 64) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n_loss; i += 64) s += loss_part[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) *loss_out = s * loss_scale;
+  }
+}
+
+// loss value alone (the autograd route reads it without stepping an optimizer)
+__global__ __launch_bounds__(64) void loss_sum_kernel(const float* __restrict__ loss_part, int n_loss, float loss_scale,
+                                                      float* __restrict__ loss_out) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n_loss; i += 64) s += loss_part[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (threadIdx.x == 0) *loss_out = s * loss_scale;
+}

@@ -121,20 +121,43 @@ SR_DEV void stage_core(T* dst, const T* __restrict__ src, int H, int W, int ty0,
 // un-shuffle the HR gradient (NCHW fp32, N x 3 x RH x RW) into a dconv tile [px][COP]:
 // channel c*R*R + i*R + j of LR pixel (Y, X) = dout[c][Y*R + i][X*R + j].  HALO = 1: tile with halo,
 // HALO = 0: core tile.
-template <typename T, typename E, int HALO, int NTHREADS = 256>
-SR_DEV void stage_dconv(T* DC, const float* __restrict__ dout, int H, int W, int ty0, int tx0, int tid) {
+// LOSS folds the trainers' loss into this read (pretrain.py:73-77 L1, train_video_superresolution.py:43-53
+// Charbonnier): `dout` is then the network OUTPUT sr, `hr` the target, and the gradient is formed on the fly,
+//   LOSS 1:  g = sign(sr - hr) * gscale           (torch's l1_loss backward; gscale = upstream / numel)
+//   LOSS 2:  g = (sr - hr) / sqrt((sr - hr)^2 + 1e-12) * gscale
+// while `lsum` collects this thread's share of sum |sr - hr| (resp. sum sqrt(d^2 + 1e-12)) over the CORE pixels
+// (each HR pixel is a core pixel of exactly one tile): the 14 MB HR gradient never exists in HBM.
+struct LossIn {
+  const float* hr;
+  float gscale;
+};
+template <int LOSS> SR_DEV float loss_grad(float q, float h, float gscale, float& term) {
+  const float d = q - h;
+  if constexpr (LOSS == 1) {
+    term = fabsf(d);
+    return d == 0.f ? 0.f : __builtin_copysignf(gscale, d);
+  } else {
+    const float s = sqrtf(d * d + 1e-12f);
+    term = s;
+    return d / s * gscale;
+  }
+}
+template <typename T, typename E, int HALO, int NTHREADS = 256, int LOSS = 0>
+SR_DEV void stage_dconv(T* DC, const float* __restrict__ dout, int H, int W, int ty0, int tx0, int tid, LossIn li = LossIn{nullptr, 0.f},
+                        float* lsum = nullptr) {
   constexpr int R = E::R;
   constexpr int NPX = HALO ? (E::NPXH_PAD + 2) : (E::NPXC + 2);
   constexpr int NLIVE = HALO ? E::NPXH : E::NPXC;
   constexpr int TWW = HALO ? E::HW : E::TW;
-  const size_t hrw = (size_t)W * R, plane = (size_t)H * R * hrw;
+  const unsigned hrw = (unsigned)W * R, plane = (unsigned)H * R * hrw;   // one image: 32-bit offsets from a uniform base
   constexpr int ROWS = 3 * R;                       // (colour, sub-row) pairs per pixel
+  constexpr int BATCH = LOSS ? (R == 2 ? 1 : 2) : SR_STAGE_BATCH;   // loads in flight per thread (the loss fold reads two tensors)
   constexpr int TOTAL = NPX * ROWS, ITER = (TOTAL + NTHREADS - 1) / NTHREADS;
 #pragma unroll
-  for (int b0 = 0; b0 < ITER; b0 += SR_STAGE_BATCH) {
-    float v[SR_STAGE_BATCH][R];
+  for (int b0 = 0; b0 < ITER; b0 += BATCH) {
+    float v[BATCH][R];
 #pragma unroll
-    for (int b = 0; b < SR_STAGE_BATCH; ++b) {
+    for (int b = 0; b < BATCH; ++b) {
       const int idx = tid + (b0 + b) * NTHREADS;
       const int p = idx / ROWS, cr = idx - p * ROWS;
       const int c = cr / R, si = cr - c * R;
@@ -144,7 +167,8 @@ SR_DEV void stage_dconv(T* DC, const float* __restrict__ dout, int H, int W, int
         const int py = p / TWW, px = p - py * TWW;
         const int Y = ty0 - HALO + py, X = tx0 - HALO + px;
         if (Y >= 0 && Y < H && X >= 0 && X < W) {
-          const float* s = dout + c * plane + ((size_t)Y * R + si) * hrw + (size_t)X * R;
+          const unsigned off = c * plane + ((unsigned)Y * R + si) * hrw + (unsigned)X * R;
+          const float* s = dout + off;
           if constexpr (R == 4) {
             const f32x4 q = *reinterpret_cast<const f32x4*>(s);
             v[b][0] = q[0]; v[b][1] = q[1]; v[b][2] = q[2]; v[b][3] = q[3];
@@ -152,11 +176,28 @@ SR_DEV void stage_dconv(T* DC, const float* __restrict__ dout, int H, int W, int
 #pragma unroll
             for (int j = 0; j < R; ++j) v[b][j] = s[j];
           }
+          if constexpr (LOSS != 0) {
+            float h[R];
+            if constexpr (R == 4) {
+              const f32x4 q = *reinterpret_cast<const f32x4*>(li.hr + off);
+              h[0] = q[0]; h[1] = q[1]; h[2] = q[2]; h[3] = q[3];
+            } else {
+#pragma unroll
+              for (int j = 0; j < R; ++j) h[j] = li.hr[off + j];
+            }
+            const bool core = !HALO || (py >= 1 && py <= E::TH && px >= 1 && px <= E::TW);
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+              float term;
+              v[b][j] = loss_grad<LOSS>(v[b][j], h[j], li.gscale, term);
+              if (core && lsum) *lsum += term;
+            }
+          }
         }
       }
     }
 #pragma unroll
-    for (int b = 0; b < SR_STAGE_BATCH; ++b) {
+    for (int b = 0; b < BATCH; ++b) {
       const int idx = tid + (b0 + b) * NTHREADS;
       if (b0 + b < ITER && idx < TOTAL) {
         const int p = idx / ROWS, cr = idx - p * ROWS;
@@ -298,20 +339,35 @@ __global__ __launch_bounds__(256) void sr_tail_fwd_kernel(const T* __restrict__ 
   }
 }
 
+// sum `v` over the workgroup (plain LDS stores, `red` = NTHREADS / 64 floats) and let thread 0 write it
+template <int NTHREADS> SR_DEV void wg_sum_store(float v, float* red, float* out, int tid) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int i = 0; i < NTHREADS / 64; ++i) t += red[i];
+    *out = t;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // tail backward-data: dfeat[px, f] = sum_{u, ch} Wt[ch, f, 8-u] dconv[px + u - 1, ch]
 // ---------------------------------------------------------------------------------------------
-template <typename T, int F, int R>
+template <typename T, int F, int R, int LOSS = 0>
 __global__ __launch_bounds__(256) void sr_tail_bwd_data_kernel(const float* __restrict__ dout, T* __restrict__ dfeat,
                                                                const T* __restrict__ wblob, int H, int W,
-                                                               int tiles_x) {
+                                                               int tiles_x, LossIn li) {
   typedef EndsCfg<F, R> E;
   typedef typename FragOf<T>::half_type HalfT;
   __shared__ __attribute__((aligned(16))) T DC[E::DC_ELEMS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int n = blockIdx.y, tile = blockIdx.x;
   const int ty0 = (tile / tiles_x) * E::TH, tx0 = (tile % tiles_x) * E::TW;
-  stage_dconv<T, E, 1>(DC, dout + (size_t)n * 3 * H * R * W * R, H, W, ty0, tx0, tid);
+  li.hr += LOSS ? (size_t)n * 3 * H * R * W * R : 0;
+  stage_dconv<T, E, 1, 256, LOSS>(DC, dout + (size_t)n * 3 * H * R * W * R, H, W, ty0, tx0, tid, li, nullptr);
   __syncthreads();
   const T* wt = wblob + (size_t)E::NT * E::KST * 512;        // backward-data section follows the forward one
   constexpr bool HOIST = (sizeof(T) == 2);
@@ -347,11 +403,11 @@ __global__ __launch_bounds__(256) void sr_tail_bwd_data_kernel(const float* __re
 // Slab per workgroup: [TAIL_TILES][16][64]; layout in packing.ends_grad_tables.
 // ---------------------------------------------------------------------------------------------
 
-template <typename T, int F, int R>
+template <typename T, int F, int R, int LOSS = 0>
 __global__ __launch_bounds__(896) void sr_tail_wgrad_kernel(const float* __restrict__ dout, const T* __restrict__ feat,
                                                             const float* __restrict__ ximg, float mean,
                                                             float* __restrict__ partial, int N, int H, int W,
-                                                            int tiles_x, int tiles_per_img) {
+                                                            int tiles_x, int tiles_per_img, LossIn li, float* __restrict__ loss_part) {
   typedef EndsCfg<F, R> E;
   typedef typename E::template Img<2> I;
   typedef typename FragOf<T>::type FragT;
@@ -367,6 +423,7 @@ __global__ __launch_bounds__(896) void sr_tail_wgrad_kernel(const float* __restr
   f32x16 acc[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) acc[i] = zero16();
+  float lsum = 0.f;
 
   SR_STAMP_DECL;
   SR_STAMP();
@@ -375,7 +432,9 @@ __global__ __launch_bounds__(896) void sr_tail_wgrad_kernel(const float* __restr
     const int ty0 = (tile / tiles_x) * E::TH, tx0 = (tile % tiles_x) * E::TW;
     __syncthreads();
     SR_STAMP();
-    stage_dconv<T, E, 0, NTHREADS>(DC, dout + (size_t)n * 3 * H * R * W * R, H, W, ty0, tx0, tid);
+    LossIn lin = li;
+    lin.hr += LOSS ? (size_t)n * 3 * H * R * W * R : 0;
+    stage_dconv<T, E, 0, NTHREADS, LOSS>(DC, dout + (size_t)n * 3 * H * R * W * R, H, W, ty0, tx0, tid, lin, &lsum);
     SR_STAMP();
     stage_halo<T, E, F, NTHREADS>(FT, feat + (size_t)n * H * W * F, H, W, ty0, tx0, tid);
     stage_img<T, E, 2, NTHREADS>(XI, ximg + (size_t)n * 3 * H * W, mean, H, W, ty0, tx0, tid);
@@ -407,6 +466,7 @@ __global__ __launch_bounds__(896) void sr_tail_wgrad_kernel(const float* __restr
   for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
     for (int i = 0; i < 16; ++i) out[((gbase + ti) * 16 + i) * 64 + lane] = acc[ti][i];
+  if constexpr (LOSS != 0) wg_sum_store<NTHREADS>(lsum, reinterpret_cast<float*>(smem), loss_part + blockIdx.x, tid);
   SR_STAMP();
 }
 
@@ -468,12 +528,12 @@ __global__ __launch_bounds__(576) void sr_head_wgrad_kernel(const T* __restrict_
 // 14 waves accumulate their weight-gradient tiles as sr_tail_wgrad_kernel does (no barrier in between: both
 // only read LDS).  Bit-identical to sr_tail_bwd_data_kernel + sr_tail_wgrad_kernel with the same grid.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int F, int R>
+template <typename T, int F, int R, int LOSS = 0>
 __global__ __launch_bounds__(896) void sr_tail_bwd_kernel(const float* __restrict__ dout, const T* __restrict__ feat,
                                                           const float* __restrict__ ximg, float mean,
                                                           const T* __restrict__ wblob, T* __restrict__ dfeat,
                                                           float* __restrict__ partial, int N, int H, int W, int tiles_x,
-                                                          int tiles_per_img) {
+                                                          int tiles_per_img, LossIn li, float* __restrict__ loss_part) {
   typedef EndsCfg<F, R> E;
   typedef typename E::template Img<2> I;
   typedef typename FragOf<T>::type FragT;
@@ -495,12 +555,20 @@ __global__ __launch_bounds__(896) void sr_tail_bwd_kernel(const float* __restric
   f32x16 acc[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) acc[i] = zero16();
+  __shared__ float lsum_lds[LOSS ? NTHREADS : 1];      // this thread's loss partial lives in LDS: no VGPR to spare here
+  if constexpr (LOSS != 0) lsum_lds[tid] = 0.f;
 
   for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
     const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
     const int ty0 = (tile / tiles_x) * E::TH, tx0 = (tile % tiles_x) * E::TW;
     __syncthreads();
-    stage_dconv<T, E, 1, NTHREADS>(DC, dout + (size_t)n * 3 * H * R * W * R, H, W, ty0, tx0, tid);
+    LossIn lin = li;
+    lin.hr += LOSS ? (size_t)n * 3 * H * R * W * R : 0;
+    {
+      float lsum = 0.f;
+      stage_dconv<T, E, 1, NTHREADS, LOSS>(DC, dout + (size_t)n * 3 * H * R * W * R, H, W, ty0, tx0, tid, lin, &lsum);
+      if constexpr (LOSS != 0) lsum_lds[tid] += lsum;
+    }
     stage_halo<T, E, F, NTHREADS>(FT, feat + (size_t)n * H * W * F, H, W, ty0, tx0, tid);
     stage_img<T, E, 2, NTHREADS>(XI, ximg + (size_t)n * 3 * H * W, mean, H, W, ty0, tx0, tid);
     __syncthreads();
@@ -527,7 +595,7 @@ __global__ __launch_bounds__(896) void sr_tail_bwd_kernel(const float* __restric
         for (int g = 0; g < E::FC; ++g) stream_store(reinterpret_cast<HalfT*>(o + g * 8 + hh * 4), acc_group<T>(d, g));
       }
     }
-    constexpr int UNR = NT > 1 ? 1 : 3;            // x4: two accumulator tiles per wave, 128-register budget
+    constexpr int UNR = (NT > 1 || (LOSS != 0 && R == 2)) ? 1 : 3;   // x4: two accumulator tiles per wave, 128-register budget
 #pragma unroll UNR
     for (int ot = 0; ot < E::NPT_O; ++ot) {
       const int toy = (ot / (E::TW / 8)) * 4, tox = (ot % (E::TW / 8)) * 8;
@@ -550,4 +618,5 @@ __global__ __launch_bounds__(896) void sr_tail_bwd_kernel(const float* __restric
   for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
     for (int i = 0; i < 16; ++i) out[((gbase + ti) * 16 + i) * 64 + lane] = acc[ti][i];
+  if constexpr (LOSS != 0) wg_sum_store<NTHREADS>(lsum_lds[tid], reinterpret_cast<float*>(smem), loss_part + blockIdx.x, tid);
 }

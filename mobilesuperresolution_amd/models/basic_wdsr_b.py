@@ -67,6 +67,7 @@ class _DeviceState:
         self.part_b = f32(lay.NB * self.wgs_body * lay.slab_b)
         self.part_tail = f32(self.wgs_tail * lay.slab_tail)
         self.part_head = f32(self.wgs_head * lay.slab_head)
+        self.loss_part = torch.zeros(self.wgs_tail, dtype=torch.float32, device=device)   # per-workgroup loss sums (loss fold)
         # static part of the C struct
         n = L.WdsrNet()
         n.F, n.NB, n.R, n.dtype, n.mean = lay.F, lay.NB, lay.R, L.DTYPE_CODE[dt], model.image_mean
@@ -88,7 +89,13 @@ class _DeviceState:
             setattr(n, k + "_sidx", self.g[k][0].data_ptr())
             setattr(n, k + "_dst", self.g[k][1].data_ptr())
             setattr(n, "n_" + k, self.g[k][0].numel())
+        n.loss_part = self.loss_part.data_ptr()
         self.net = n
+
+    def call_struct(self) -> "L.WdsrNet":
+        """a private copy of the C struct for ONE call: forward runs on the caller's thread, backward on autograd's, and
+        neither may see the other's per-call fields"""
+        return L.WdsrNet.from_buffer_copy(self.net)
 
 
 class BASIC_MODEL(nn.Module):
@@ -111,6 +118,22 @@ class BASIC_MODEL(nn.Module):
         self.layout = get_layout(f, nb, self.scale)
         self.flat = nn.Parameter(self._reference_init())
         self._dev = {}
+
+    # ---- the per-device state holds ctypes pointers and device work buffers: never pickled or deep-copied (the reference
+    # trainers pickle whole modules, train_video_superresolution.py:306; EMA / best-model copies use deepcopy) ----
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_dev"] = {}
+        return d
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = {} if k == "_dev" else copy.deepcopy(v, memo)
+        return new
 
     # ---- initial values exactly as the reference constructs them (same RNG draws, same constants) ----
     def _reference_init(self) -> torch.Tensor:
@@ -168,9 +191,13 @@ class BASIC_MODEL(nn.Module):
             st = self._dev[key] = _DeviceState(self, device)
         return st
 
-    def _check_input(self, x):
+    def _check_input(self, x, *others):
         if not x.is_cuda or not self.flat.is_cuda:
             raise L.HotpathError("BASIC_MODEL (MI355X hot path) needs CUDA/HIP tensors; there is no CPU fallback")
+        for t in (self.flat,) + others:
+            if t.device != x.device:
+                raise L.HotpathError(f"tensors on different devices ({x.device} vs {t.device}): the kernels take raw pointers "
+                                     "and would dereference another GPU's memory")
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError(f"expected N x 3 x H x W input, got {tuple(x.shape)}")
         if x.requires_grad:
@@ -184,7 +211,7 @@ class BASIC_MODEL(nn.Module):
         slots = lay.NB + 1 if save_acts else 2
         acts = torch.empty((slots, n, h, w, lay.F), dtype=self.hot_dtype, device=x.device)
         out = torch.empty((n, 3, self.scale * h, self.scale * w), dtype=torch.float32, device=x.device)
-        net = st.net
+        net = st.call_struct()
         net.N, net.H, net.W = n, h, w
         net.flat, net.x, net.acts, net.out = flat.data_ptr(), x.data_ptr(), acts.data_ptr(), out.data_ptr()
         side = None
@@ -197,7 +224,8 @@ class BASIC_MODEL(nn.Module):
         key = (flat.data_ptr(), flat._version)
         static = getattr(self, "assume_static_weights", False) and not save_acts and st.packed_key == key
         flags = (1 if save_acts else 0) | (2 if static else 0)
-        L.launch("sr_wdsr_net_forward", L.lib().sr_wdsr_net_forward, ctypes.byref(net), flags, L.stream_ptr())
+        with torch.cuda.device(x.device):
+            L.launch("sr_wdsr_net_forward", L.lib().sr_wdsr_net_forward, ctypes.byref(net), flags, L.stream_ptr(x.device))
         st.packed_key = key
         return out, acts, side
 
@@ -218,6 +246,123 @@ class BASIC_MODEL(nn.Module):
             return _NetFunction.apply(x, self.flat, self)
         return self._forward_impl(x, self.flat.detach(), False)[0]
 
+    # ---- loss / optimizer epilogue on the hot path; the plain forward() / loss.backward() route above
+    # keeps working unchanged ----
+    _LOSS_KINDS = {"l1": 1, "charbonnier": 2}
+
+    @staticmethod
+    def _gscale(weight: float, numel: int) -> float:
+        """upstream gradient / numel as torch's mean-reduced loss backward forms it: an fp32 division of fp32 values"""
+        return float(np.float32(weight) / np.float32(numel))
+
+    def _loss_backward_impl(self, x, hr, flat, kind: str, weight: float, net_out=None):
+        """forward + backward with the loss folded into the tail backward (no HR gradient tensor, no loss kernels).
+        Returns (net struct ready for the Adam call, out, gflat, keepalive)."""
+        st = self._state(x.device)
+        out, acts, side = self._forward_impl(x, flat, True)
+        grads = torch.empty_like(acts)
+        gflat = torch.empty_like(flat)
+        dtsave = torch.empty_like(side) if side is not None else None
+        net = st.call_struct()
+        net.N, net.H, net.W = x.shape[0], x.shape[2], x.shape[3]
+        net.flat, net.gflat, net.x = flat.data_ptr(), gflat.data_ptr(), x.data_ptr()
+        net.acts, net.grads, net.out = acts.data_ptr(), grads.data_ptr(), out.data_ptr()
+        net.tsave = side.data_ptr() if side is not None else None
+        net.dtsave = dtsave.data_ptr() if dtsave is not None else None
+        net.hr, net.loss_kind, net.loss_gscale = hr.data_ptr(), self._LOSS_KINDS[kind], self._gscale(weight, out.numel())
+        with torch.cuda.device(x.device):
+            L.launch("sr_wdsr_net_backward", L.lib().sr_wdsr_net_backward, ctypes.byref(net), L.stream_ptr(x.device))
+        return net, out, gflat, (acts, grads, side, dtsave)
+
+    def _check_target(self, x, hr):
+        self._check_input(x, hr)
+        want = (x.shape[0], 3, self.scale * x.shape[2], self.scale * x.shape[3])
+        if tuple(hr.shape) != want:
+            raise ValueError(f"target shape {tuple(hr.shape)} != network output shape {want}")
+        return x.contiguous().float(), hr.contiguous().float()
+
+    def loss(self, x: torch.Tensor, hr: torch.Tensor, kind: str = "l1", weight: float = 1.0) -> torch.Tensor:
+        """weight * L1(model(x), hr) (pretrain.py:73-75) or weight * Charbonnier (train_video_superresolution.py:43-53,
+        eps 1e-12) as a differentiable scalar: `model.loss(lr, hr).backward()` fills `flat.grad` exactly like
+        `F.l1_loss(model(lr), hr).backward()`, but the loss gradient is formed inside the tail backward kernel."""
+        x, hr = self._check_target(x, hr)
+        return _NetLossFunction.apply(x, hr, self.flat, self, kind, float(weight))
+
+    def make_train_state(self, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+        """Adam state for train_step (pretrain.py:137 hyper-parameters by default); `state.lr` may be changed between
+        steps (MultiStepLR, pretrain.py:139-142)."""
+        return AdamState(self.flat, lr, betas, eps)
+
+    def train_step(self, x: torch.Tensor, hr: torch.Tensor, state: "AdamState", kind: str = "l1", weight: float = 1.0):
+        """One whole training step -- forward, loss, backward, Adam -- in ONE call into libsr_hotpath.so; `flat` is updated
+        in place.  Returns the loss as a device scalar (no host sync; `.item()` it when pretrain.py:82 would)."""
+        x, hr = self._check_target(x, hr)
+        if state.exp_avg.device != x.device:
+            raise L.HotpathError("optimizer state and input on different devices")
+        st = self._state(x.device)
+        flat = self.flat.detach()
+        lay = self.layout
+        n, _, h, w = x.shape
+        acts = torch.empty((lay.NB + 1, n, h, w, lay.F), dtype=self.hot_dtype, device=x.device)
+        grads = torch.empty_like(acts)
+        out = torch.empty((n, 3, self.scale * h, self.scale * w), dtype=torch.float32, device=x.device)
+        gflat = torch.empty_like(flat)
+        side = dtsave = None
+        if self._saves_side_images():
+            side = torch.empty(self._side_shape(n, h, w), dtype=self.hot_dtype, device=x.device)
+            dtsave = torch.empty_like(side)
+        net = st.call_struct()
+        net.N, net.H, net.W = n, h, w
+        net.flat, net.gflat, net.x = flat.data_ptr(), gflat.data_ptr(), x.data_ptr()
+        net.acts, net.grads, net.out = acts.data_ptr(), grads.data_ptr(), out.data_ptr()
+        net.tsave = side.data_ptr() if side is not None else None
+        net.dtsave = dtsave.data_ptr() if dtsave is not None else None
+        net.hr, net.loss_kind, net.loss_gscale = hr.data_ptr(), self._LOSS_KINDS[kind], self._gscale(weight, out.numel())
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        scal = state.next_scalars()
+        with torch.cuda.device(x.device):
+            L.launch("sr_wdsr_net_train_step", L.lib().sr_wdsr_net_train_step, ctypes.byref(net), state.exp_avg.data_ptr(),
+                     state.exp_avg_sq.data_ptr(), flat.numel(), ctypes.byref(scal), float(weight) / out.numel(), loss.data_ptr(),
+                     L.stream_ptr(x.device))
+        _bump_version(self.flat)
+        st.packed_key = None                         # the blobs no longer match `flat`
+        return loss
+
+
+def _bump_version(t: torch.Tensor):
+    """`flat` was written through its raw pointer: tell autograd (in-place version counter) without launching anything"""
+    try:
+        torch.autograd.graph.increment_version(t)
+    except AttributeError:                           # older torch
+        t.data.add_(0)
+
+
+class AdamState:
+    """exp_avg / exp_avg_sq / step of torch.optim.Adam for the single flat parameter"""
+
+    def __init__(self, flat: torch.Tensor, lr: float, betas, eps: float):
+        self.lr, self.beta1, self.beta2, self.eps = float(lr), float(betas[0]), float(betas[1]), float(eps)
+        self.step = 0
+        self.exp_avg = torch.zeros_like(flat, memory_format=torch.preserve_format).detach()
+        self.exp_avg_sq = torch.zeros_like(self.exp_avg)
+
+    def next_scalars(self) -> "L.AdamScalars":
+        """the scalars torch.optim.Adam hands its kernels at this step: computed in double, rounded to float"""
+        self.step += 1
+        bc1 = 1.0 - self.beta1 ** self.step
+        bc2 = 1.0 - self.beta2 ** self.step
+        return L.AdamScalars(1.0 - self.beta1, self.beta2, 1.0 - self.beta2, math.sqrt(bc2), self.eps, -(self.lr / bc1))
+
+    def state_dict(self):
+        return {"step": self.step, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr,
+                "betas": (self.beta1, self.beta2), "eps": self.eps}
+
+    def load_state_dict(self, d):
+        self.step, self.lr, self.eps = int(d["step"]), float(d["lr"]), float(d["eps"])
+        self.beta1, self.beta2 = (float(b) for b in d["betas"])
+        self.exp_avg.copy_(d["exp_avg"])
+        self.exp_avg_sq.copy_(d["exp_avg_sq"])
+
 
 class _NetFunction(torch.autograd.Function):
     """Whole-network forward/backward in two C calls.  Saves the block inputs (bf16 or fp32 NHWC); the
@@ -226,22 +371,51 @@ class _NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, flat, model):
         out, acts, tsave = model._forward_impl(x, flat, True)
-        ctx.model, ctx.x, ctx.acts, ctx.flat, ctx.tsave = model, x, acts, flat, tsave
+        ctx.model, ctx.x, ctx.acts, ctx.tsave = model, x, acts, tsave
+        ctx.save_for_backward(flat)                  # autograd's version check: an optimizer step between forward and
+        ctx.packed_key = model._state(x.device).packed_key   # backward raises instead of mixing old activations with new weights
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        model, x, acts, flat = ctx.model, ctx.x, ctx.acts, ctx.flat
+        model, x, acts = ctx.model, ctx.x, ctx.acts
+        (flat,) = ctx.saved_tensors
         st = model._state(x.device)
         dout = dout.contiguous().float()
         grads = torch.empty_like(acts)
         gflat = torch.empty_like(flat)
-        net = st.net
+        net = st.call_struct()
         net.N, net.H, net.W = x.shape[0], x.shape[2], x.shape[3]
         net.flat, net.gflat, net.x = flat.data_ptr(), gflat.data_ptr(), x.data_ptr()
         net.acts, net.grads, net.dout = acts.data_ptr(), grads.data_ptr(), dout.data_ptr()
         dtsave = torch.empty_like(ctx.tsave) if ctx.tsave is not None else None
         net.tsave = ctx.tsave.data_ptr() if ctx.tsave is not None else None
         net.dtsave = dtsave.data_ptr() if dtsave is not None else None
-        L.launch("sr_wdsr_net_backward", L.lib().sr_wdsr_net_backward, ctypes.byref(net), L.stream_ptr())
+        with torch.cuda.device(x.device):
+            if st.packed_key != ctx.packed_key:      # another forward re-packed the per-device blobs meanwhile: pack ours again
+                L.launch("sr_wdsr_net_forward", L.lib().sr_wdsr_net_forward, ctypes.byref(net), 4, L.stream_ptr(x.device))
+                st.packed_key = ctx.packed_key
+            L.launch("sr_wdsr_net_backward", L.lib().sr_wdsr_net_backward, ctypes.byref(net), L.stream_ptr(x.device))
         return None, gflat, None
+
+
+class _NetLossFunction(torch.autograd.Function):
+    """loss(model(x), hr) as one node: forward AND backward of the network run inside forward() (the loss gradient is
+    formed in the tail backward kernel, which also emits the loss sums); backward() scales the stored parameter
+    gradient by the upstream scalar."""
+
+    @staticmethod
+    def forward(ctx, x, hr, flat, model, kind, weight):
+        net, out, gflat, _keep = model._loss_backward_impl(x, hr, flat, kind, weight)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        st = model._state(x.device)
+        with torch.cuda.device(x.device):
+            L.launch("sr_loss_value", L.lib().sr_loss_value, st.loss_part.data_ptr(), st.wgs_tail, weight / out.numel(),
+                     loss.data_ptr(), L.stream_ptr(x.device))
+        ctx.save_for_backward(gflat)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (gflat,) = ctx.saved_tensors
+        return None, None, gflat * gloss, None, None, None

@@ -78,6 +78,14 @@ if args.step:
     for _ in range(20): step()
     L.set_timer(None)
     out["step_ms"] = round(t * 1e3, 4)
+    st = m.make_train_state(lr=1e-3)
+    for _ in range(5): m.train_step(x, hr, st)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(50): m.train_step(x, hr, st)
+    torch.cuda.synchronize(); out["fused_step_ms"] = round((time.perf_counter() - t0) / 50 * 1e3, 4)
+    t0 = time.perf_counter()
+    for _ in range(50): m.train_step(x, hr, st).item()
+    out["fused_step_with_item_ms"] = round((time.perf_counter() - t0) / 50 * 1e3, 4)
     out["calls_us"] = {k: round(v[1] * 1e3, 1) for k, v in timer.summary().items()}
     with torch.no_grad():
         m.eval()
