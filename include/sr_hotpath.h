@@ -239,6 +239,12 @@ int sr_wdsr_net_forward(const sr_wdsr_net_t* net, int flags, sr_stream_t stream)
 /* full backward: d(loss)/d(out) -> gflat (gradient of every parameter in the flat buffer). */
 int sr_wdsr_net_backward(const sr_wdsr_net_t* net, sr_stream_t stream);
 
+/* Standalone nn.PixelShuffle(r) (models/basic_wdsr_b.py:80-83; basicvsr_arch_origin.py:37,87-88), NCHW fp32, bit-exact:
+ * out[n, c, h r + i, w r + j] = in[n, c r^2 + i r + j, h, w].  C = channels of the shuffled tensor, H x W = size before
+ * the shuffle.  inverse != 0 runs the inverse permutation (pixel_unshuffle = the op's backward): in is then the
+ * N x C x rH x rW tensor and out the N x C r^2 x H x W one. */
+int sr_pixel_shuffle(const float* in, float* out, int N, int C, int H, int W, int r, int inverse, sr_stream_t stream);
+
 /* Tail backward with the loss folded in (see sr_wdsr_net_t.hr): sr = network output, hr = target. */
 int sr_tail_bwd_loss(const float* sr, const float* hr, int loss_kind, float gscale, float* loss_part, const void* feat,
                      const float* x_nchw, float mean, const void* wblob, void* dfeat, float* partial, int wgs, int N, int H,

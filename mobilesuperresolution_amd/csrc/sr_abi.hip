@@ -10,6 +10,7 @@
 #include "nas_block.h"
 #include "flow_warp.h"
 #include "train_step.h"
+#include "pixel_shuffle.h"
 
 extern "C" int sr_abi_version(void) { return 4; }
 
@@ -789,6 +790,22 @@ extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) 
   const int cb = (n->n_chan + 3) / 4, bb = (n->n_bias + 255) / 256;
   hipLaunchKernelGGL(wn_bwd_kernel, dim3(cb + bb), dim3(256), 0, st, n->flat, n->dsrc, n->gflat,
                      (const int4*)n->chan_tab, n->n_chan, n->bias_tab, n->n_bias, cb);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// standalone PixelShuffle
+// ------------------------------------------------------------------------------------------
+extern "C" int sr_pixel_shuffle(const float* in, float* out, int N, int C, int H, int W, int r, int inverse, sr_stream_t stream) {
+  if (!in || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || r < 1 || r > 8) return -2;
+  const long total4 = inverse ? (long)N * C * r * r * H * ((W + 3) / 4) : (long)N * C * (H * r) * ((W * r + 3) / 4);
+  const long blocks = (total4 + 255) / 256;
+  if (blocks > 0x7fffffffL) return -2;
+  if (inverse)
+    hipLaunchKernelGGL((pixel_shuffle_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, C, H, W, r, total4);
+  else
+    hipLaunchKernelGGL((pixel_shuffle_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, C, H, W, r, total4);
   SR_HIP_CHECK_LAUNCH();
   return 0;
 }

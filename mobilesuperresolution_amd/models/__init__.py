@@ -7,11 +7,13 @@ import argparse
 
 from .basic_wdsr_b import BASIC_MODEL
 from .basicvsr_arch import ConvResidualBlocks, ResidualBlockNoBN
+from .basicvsr_arch_origin import BasicVSR_origin, pixel_shuffle
+from .mvvsr_arch import MotionVectorVSR
 from .spynet_arch import flow_warp
 from .wdsr_b import NAS_MODEL, ModelOutput
 
-__all__ = ["BASIC_MODEL", "NAS_MODEL", "ModelOutput", "ConvResidualBlocks", "ResidualBlockNoBN", "flow_warp", "get_model",
-           "update_argparser"]
+__all__ = ["BASIC_MODEL", "NAS_MODEL", "ModelOutput", "ConvResidualBlocks", "ResidualBlockNoBN", "MotionVectorVSR",
+           "BasicVSR_origin", "flow_warp", "pixel_shuffle", "get_model", "update_argparser"]
 
 _REGISTRY = {"BASIC_MODEL": BASIC_MODEL, "NAS_MODEL": NAS_MODEL}
 
@@ -24,6 +26,17 @@ def update_argparser(parser: argparse.ArgumentParser):
     parser.add_argument('--length_search', action='store_true', default=False)
     parser.add_argument('--num_blocks', help='Number of residual blocks in networks.', default=16, type=int)
     parser.add_argument('--num_residual_units', help='Number of residual units in networks.', default=24, type=int)
+    # registered by the reference and read by nobody on this path (models/__init__.py:18-28); kept so that the
+    # trainers' command lines parse unchanged
+    parser.add_argument('--seperate', help='seperate conv', default=False, type=int)
+    parser.add_argument('--bottleneck_type', help='inverted_bottle', default='inverted_bottle', type=str)
+    parser.add_argument('--clip_range', help='weight clip range.', default=None, type=float)
+    parser.add_argument('--trainable_clip', action='store_true', default=False, help='trainable clip.')
+    parser.add_argument('--clip_quantile_lb', help='weight clip quantile lower bound.', default=None, type=float)
+    parser.add_argument('--clip_quantile_ub', help='weight clip quantile upper bound.', default=None, type=float)
+    parser.add_argument('--clip_range_tail', help='weight clip range for tail layer.', default=None, type=float)
+    parser.add_argument('--clip_range_skip', help='weight clip range for skip layer.', default=None, type=float)
+    parser.add_argument('--clip_scale', help='weight clip scale factor for quantile clipping.', default=1.0, type=float)
     parser.add_argument('--hot_dtype', help='MI355X hot-path storage/compute type: fp32 (exact) or bf16.',
                         default=None, type=str)
 

@@ -7,7 +7,11 @@ num_block x [x + conv2(relu(conv1(x)))]; plain convs with bias, PyTorch-default 
 `main.0.{weight,bias}`, `main.2.{i}.conv{1,2}.{weight,bias}`.  Input/output are NCHW fp32 like the
 reference's (it is called on `torch.cat([x_i, feat_prop], 1)` inside the propagation loops,
 basicvsr_arch.py:67-88); every convolution, activation, residual add and their backward run in
-csrc/conv3x3.h.  Supported: num_out_ch = 24, num_in_ch in {24, 27}.  No CPU / ATen fallback.
+csrc/conv3x3.h.  The kernels are 24 features wide; a narrower trunk (the trainer's MotionVectorVSR uses
+num_feat = 20, train_video_superresolution.py:251) is embedded exactly: its parameters keep the reference shapes and
+are scattered into the 24-wide layout with zero rows / columns, whose channels stay exactly zero through every
+LeakyReLU / ReLU / residual add.  Supported: num_out_ch <= 24, num_in_ch in {num_out_ch, num_out_ch + 3}.
+No CPU / ATen fallback.
 
 `propagate(...)` restates the two recurrent loops of MotionVectorVSR.forward (mvvsr_arch.py:72-93) around
 the trunk; flow_warp itself is the next row of SURVEY 8(f) and is taken as a callable.
@@ -92,10 +96,11 @@ class ConvResidualBlocks(nn.Module):
 
     def __init__(self, num_in_ch=3, num_out_ch=64, num_block=15, hot_dtype=None):
         super().__init__()
-        if num_out_ch != 24 or num_in_ch not in (24, 27):
-            raise NotImplementedError("MI355X hot path supports ConvResidualBlocks(num_in_ch in {24,27}, 24, n) "
+        if not (1 <= num_out_ch <= 24) or num_in_ch not in (num_out_ch, num_out_ch + 3):
+            raise NotImplementedError("MI355X hot path supports ConvResidualBlocks(F or F + 3, F, n) with F <= 24 "
                                       f"(got {num_in_ch}, {num_out_ch}); there is no generic fallback")
         self.num_in_ch, self.num_feat, self.num_block = num_in_ch, num_out_ch, num_block
+        self.cin_k = 27 if num_in_ch == num_out_ch + 3 else 24      # input width of the first conv as the kernels see it
         name = hot_dtype or os.environ.get("SR_HOT_DTYPE", "fp32")
         self.hot_dtype = name if isinstance(name, torch.dtype) else _DTYPES[str(name).lower().replace("float32", "fp32").replace("bfloat16", "bf16")]
         # same constructor calls, in the same order, as the reference (same RNG draws); then flattened
@@ -107,6 +112,34 @@ class ConvResidualBlocks(nn.Module):
             vals.append(t.detach().reshape(-1))
             off += t.numel()
         self.flat = nn.Parameter(torch.cat(vals).float())
+        self._pad = None
+        if num_out_ch < 24:                                  # scatter / gather tables between the real and the 24-wide layout
+            f, cin, ck = num_out_ch, num_in_ch, self.cin_k
+            real = torch.arange(self.flat.numel(), dtype=torch.int64)
+            zero = self.flat.numel()                          # index of the appended 0
+            pads, off = [], 0
+            for k in range(1 + 2 * num_block):
+                ci_r, ci_p = (cin, ck) if k == 0 else (f, 24)
+                wp = torch.full((24, ci_p, 3, 3), zero, dtype=torch.int64)
+                wp[:f, :ci_r] = real[off:off + f * ci_r * 9].view(f, ci_r, 3, 3)
+                off += f * ci_r * 9
+                bp = torch.full((24,), zero, dtype=torch.int64)
+                bp[:f] = real[off:off + f]
+                off += f
+                pads += [wp.reshape(-1), bp]
+            pad_idx = torch.cat(pads)
+            inv = torch.empty(self.flat.numel(), dtype=torch.int64)
+            pos = torch.nonzero(pad_idx != zero).squeeze(1)
+            inv[pad_idx[pos]] = pos
+            self.register_buffer("_pad_idx", pad_idx, persistent=False)
+            self.register_buffer("_unpad_idx", inv, persistent=False)
+            self._pad = True
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d.pop("_blob", None)
+        d.pop("_blob_key", None)
+        return d
 
     # ---- reference-compatible checkpoints ----
     def named_tensors(self, source=None):
@@ -145,9 +178,12 @@ class ConvResidualBlocks(nn.Module):
         key = (self.hot_dtype, flat.data_ptr(), flat._version)
         if getattr(self, "_blob_key", None) != key:
             dev = flat.device
-            tabs = _trunk_tables(self.num_in_ch, self.num_block,
+            tabs = _trunk_tables(self.cin_k, self.num_block,
                                  dev.index if dev.index is not None else torch.cuda.current_device())
-            self._blob = torch.cat([flat.detach(), tabs[3]]).index_select(0, tabs[0]).to(self.hot_dtype)
+            fl = flat.detach()
+            if self._pad:
+                fl = torch.cat([fl, fl.new_zeros(1)]).index_select(0, self._pad_idx)
+            self._blob = torch.cat([fl, tabs[3]]).index_select(0, tabs[0]).to(self.hot_dtype)
             self._blob_key = key
         return self._blob
 
@@ -171,22 +207,22 @@ class _TrunkFunction(torch.autograd.Function):
         dt, nb, cin = mod.hot_dtype, mod.num_block, mod.num_in_ch
         n, _, h, w = fea.shape
         dev = fea.device
-        ci0 = 32 if cin == 27 else 24
+        ci0 = 32 if mod.cin_k == 27 else 24
         if ci0 != cin:
             x0 = torch.zeros((n, h, w, ci0), dtype=dt, device=dev)
             x0[..., :cin] = fea.detach().permute(0, 2, 3, 1)
         else:
             x0 = fea.detach().permute(0, 2, 3, 1).to(dt).contiguous()
         blob = mod._packed(flat)
-        tabs = _trunk_tables(cin, nb, dev.index if dev.index is not None else torch.cuda.current_device())
+        tabs = _trunk_tables(mod.cin_k, nb, dev.index if dev.index is not None else torch.cuda.current_device())
         acts = torch.empty((nb + 1, n, h, w, 24), dtype=dt, device=dev)              # a_0 .. a_nb
         mids = torch.empty((max(nb, 1), n, h, w, 24), dtype=dt, device=dev)          # t_i = relu(conv1(a_i))
         _launch("sr_c3_trunk_fwd", x0.data_ptr(), acts.data_ptr(), mids.data_ptr(), blob.data_ptr(), tabs[2], nb, n, h, w,
                 ci0, L.DTYPE_CODE[dt])
         ctx.mod, ctx.x0, ctx.acts, ctx.mids, ctx.blob = mod, x0, acts, mids, blob
         ctx.need_dx = fea.requires_grad
-        out = torch.empty((n, 24, h, w), dtype=torch.float32, device=dev)
-        out.copy_(acts[nb].permute(0, 3, 1, 2))                 # NHWC hot dtype -> NCHW fp32 in one kernel
+        out = torch.empty((n, mod.num_feat, h, w), dtype=torch.float32, device=dev)
+        out.copy_(acts[nb][..., :mod.num_feat].permute(0, 3, 1, 2))      # NHWC hot dtype -> NCHW fp32 in one kernel
         return out
 
     @staticmethod
@@ -196,10 +232,14 @@ class _TrunkFunction(torch.autograd.Function):
         n, h, w, ci0 = x0.shape
         dev = x0.device
         wgs = 64
-        _, grad_idx, boff, _ = _trunk_tables(cin, nb, dev.index if dev.index is not None else torch.cuda.current_device())
+        _, grad_idx, boff, _ = _trunk_tables(mod.cin_k, nb, dev.index if dev.index is not None else torch.cuda.current_device())
         ga = torch.empty_like(acts)                                                  # gradient at a_0 .. a_nb
         gt = torch.empty_like(mids)
-        ga[nb] = dy.permute(0, 2, 3, 1)
+        if mod.num_feat < 24:
+            ga[nb].zero_()
+            ga[nb][..., :mod.num_feat] = dy.permute(0, 2, 3, 1)
+        else:
+            ga[nb] = dy.permute(0, 2, 3, 1)
         parts = torch.empty((1 + 2 * nb, wgs, 9 * 1024), dtype=torch.float32, device=dev)
         dx0 = torch.empty_like(x0) if ctx.need_dx else None
         _launch("sr_c3_trunk_bwd", x0.data_ptr(), acts.data_ptr(), mids.data_ptr(), ga.data_ptr(), gt.data_ptr(),
@@ -210,6 +250,8 @@ class _TrunkFunction(torch.autograd.Function):
             dfea = torch.empty((n, cin, h, w), dtype=torch.float32, device=dev)
             dfea.copy_(dx0[..., :cin].permute(0, 3, 1, 2))
         gflat = parts.sum(1).reshape(-1).index_select(0, grad_idx)                   # dW | db of every conv, flat order
+        if mod._pad:
+            gflat = gflat.index_select(0, mod._unpad_idx)
         return dfea, None, gflat
 
 

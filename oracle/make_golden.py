@@ -233,6 +233,196 @@ def g7_g8_vsr():
     print("G8 ok")
 
 
+def _mmedit_stubs():
+    """models/{basicvsr_arch,basicvsr_arch_origin,mvvsr_arch}.py hard-import mmedit (absent here): map the
+    imported names onto the vendored copies in models/spynet_arch.py so the module bodies execute."""
+    import models.spynet_arch as sp
+    for name in ("mmedit", "mmedit.models", "mmedit.models.common", "mmedit.models.backbones",
+                 "mmedit.models.backbones.sr_backbones", "mmedit.models.backbones.sr_backbones.basicvsr_net",
+                 "mmedit.utils", "mmedit.models.registry"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["mmedit.models.common"].flow_warp = sp.flow_warp
+    sys.modules["mmedit.models.common"].PixelShufflePack = None
+    sys.modules["mmedit.models.backbones.sr_backbones.basicvsr_net"].SPyNet = lambda pretrained=None: sp.SpyNet(None)
+    sys.modules["mmedit.models.backbones.sr_backbones.basicvsr_net"].ResidualBlocksWithInputConv = None
+    return sp
+
+
+def g10_nas_model():
+    """Whole reference NAS_MODEL (models/wdsr_b.py:30-137): forward + L1 + speed loss (search.py:71-81, utils/loss.py)
+    + backward in train mode, forward in eval mode, one block gated off (alpha1 >= alpha2), partial global and split
+    masks.  Two environment shims only, both about the CUDA-saved latency MLP that the forward never uses
+    (speed_estimator.py:37-42): torch.load gets map_location='cpu', weights_only=True; Tensor.cuda is the identity
+    for the `kernels` constant at speed_estimator.py:68."""
+    import models.wdsr_b as wdsr_b
+    from utils.loss import SpeedLoss
+    from speed_models.helpers import get_ori_speed
+    real_load, real_cuda = torch.load, torch.Tensor.cuda
+    torch.load = lambda f, *a, **k: real_load(f, map_location="cpu", weights_only=True)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        torch.manual_seed(100)
+        ns = _params(num_blocks=4, num_residual_units=24, width_search=True, pretrained=False)
+        m = wdsr_b.NAS_MODEL(ns).train()
+        g = torch.Generator().manual_seed(101)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if "speed_estimator" in n:
+                    continue
+                if n.endswith("bias"):
+                    p.copy_(0.05 * torch.randn(p.shape, generator=g))
+                elif n.endswith("weight_g"):
+                    p.mul_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+            m.mask.weight.copy_(torch.rand(24, 1, 1, 1, generator=g) * 0.7 + 0.25)      # some global channels off
+            for blk in m.body:
+                blk.split.weight.copy_(torch.rand(24, 1, 1, 1, generator=g) * 0.7 + 0.2)
+            m.body[1].alpha1.fill_(1.5)                                                 # block 1 gated off
+        x = torch.rand(2, 3, 20, 28, generator=g)
+        hr = torch.rand(2, 3, 80, 112, generator=g)
+        d = {"x": _np(x), "hr": _np(hr)}
+        for k, v in m.state_dict().items():
+            if "speed_estimator" not in k:
+                d["p/" + k] = _np(v)
+        ori = get_ori_speed(4, 24)
+        target = 0.5 * ori
+        crit = SpeedLoss(scale=float(ori - target))
+        out, speed = m(x)
+        l1 = torch.nn.functional.l1_loss(out, hr)
+        ls = crit(speed=speed, target=target, gamma=0.1, method="clamp")
+        (1.0 * l1 + ls).backward()
+        d.update(out_train=_np(out), speed_train=_np(speed), loss_l1=_np(l1), loss_speed=_np(ls),
+                 ori_speed=np.float32(ori), speed_target=np.float32(target))
+        for n, p in m.named_parameters():
+            if "speed_estimator" in n or p.grad is None:
+                continue
+            d["g/" + n] = _np(p.grad)
+        for k, v in m.state_dict().items():                    # beta1 / beta2 are rewritten inside forward (:534)
+            if k.endswith(("beta1", "beta2")):
+                d["after/" + k] = _np(v)
+        m.eval()
+        with torch.no_grad():
+            oe, se = m(x)
+        d.update(out_eval=_np(oe), speed_eval=_np(se), current_blocks=np.int32(m.get_current_blocks()),
+                 block_status=np.array(m.get_block_status(), dtype=np.int32))
+        np.savez_compressed(os.path.join(OUT, "g10_nas_model.npz"), **d)
+        print("G10 ok: speed", float(speed), "eval speed", float(se), "blocks", m.get_current_blocks(),
+              "grads", sum(1 for k in d if k.startswith("g/")))
+    finally:
+        torch.load, torch.Tensor.cuda = real_load, real_cuda
+
+
+def g11_g12_video_models():
+    """G11: the reference MotionVectorVSR (models/mvvsr_arch.py:11-109, the trainer's 'basic_mv' model,
+    train_video_superresolution.py:251: num_feat=20, num_block=8) on a 2 x 4-frame clip with motion vectors: output,
+    per-frame trunk features of both directions (forward hooks), input gradient, every parameter gradient.
+    G12: BasicVSR_origin (models/basicvsr_arch_origin.py:10-95) with its SPyNet flow estimate (out of scope) replaced
+    by the same given flows: pins the propagation loops with 24 features and the PixelShuffle(2) x 2 upsampler."""
+    _mmedit_stubs()
+    import models.mvvsr_arch as mv
+    import models.basicvsr_arch_origin as bo
+    import warnings
+    torch.manual_seed(110)
+    m = mv.MotionVectorVSR(num_feat=20, num_block=2, spynet_path=None).train()
+    g = torch.Generator().manual_seed(111)
+    b, n, h, w = 2, 3, 12, 16
+    frames = torch.rand(b, n, 3, h, w, generator=g)
+    mvs = torch.rand(b, n, 2, h, w, generator=g) * 5 - 2.5
+    x = torch.cat([frames, mvs], dim=2).requires_grad_(True)
+    feats = {"backward_trunk": [], "forward_trunk": []}
+    hooks = [getattr(m, k).register_forward_hook(lambda mod, i, o, k=k: feats[k].append(o.detach().clone())) for k in feats]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = m(x, 4 * h, 4 * w)
+    tgt = torch.rand(out.shape, generator=g)
+    loss = torch.sqrt((out - tgt) ** 2 + 1e-12).mean()          # Charbonnier, train_video_superresolution.py:43-53
+    loss.backward()
+    for hk in hooks:
+        hk.remove()
+    d = {"x": _np(x), "target": _np(tgt), "out": _np(out), "loss": _np(loss), "dx": _np(x.grad),
+         "feat_backward": _np(torch.stack(feats["backward_trunk"], 1)),      # in call order: frame n-1 .. 0
+         "feat_forward": _np(torch.stack(feats["forward_trunk"], 1))}
+    for k, p in m.named_parameters():
+        if k.startswith("spynet"):
+            continue
+        d["p/" + k] = _np(p)
+        if p.grad is not None:
+            d["g/" + k] = _np(p.grad)
+    np.savez_compressed(os.path.join(OUT, "g11_mvvsr.npz"), **d)
+    print("G11 ok", tuple(out.shape), "loss", float(loss))
+
+    torch.manual_seed(120)
+    m2 = bo.BasicVSR_origin(num_feat=24, num_block=2, spynet_path=None).train()
+    ff = torch.rand(b, n - 1, 2, h, w, generator=g) * 4 - 2
+    fb = torch.rand(b, n - 1, 2, h, w, generator=g) * 4 - 2
+    m2.get_flow = lambda x: (ff, fb)                              # SPyNet is out of scope: flows are given
+    x2 = frames.clone().requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out2 = m2(x2, 4 * h, 4 * w)
+    tgt2 = torch.rand(out2.shape, generator=g)
+    loss2 = torch.sqrt((out2 - tgt2) ** 2 + 1e-12).mean()
+    loss2.backward()
+    d = {"x": _np(x2), "flows_forward": _np(ff), "flows_backward": _np(fb), "target": _np(tgt2), "out": _np(out2),
+         "loss": _np(loss2), "dx": _np(x2.grad)}
+    for k, p in m2.named_parameters():
+        if k.startswith("spynet"):
+            continue
+        d["p/" + k] = _np(p)
+        if p.grad is not None:
+            d["g/" + k] = _np(p.grad)
+    np.savez_compressed(os.path.join(OUT, "g12_basicvsr_origin.npz"), **d)
+    print("G12 ok", tuple(out2.shape), "loss", float(loss2))
+
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from set5_like import SET5_SHAPES, set5_like_hr  # noqa: E402
+
+
+def g13_set5_shaped(BASIC_MODEL):
+    """Set5 is absent offline, so PSNR parity is pinned on five synthetic images with Set5's shapes.  LR is
+    made by the reference's own numpy MATLAB-imresize clone (third_party/matlab_imresize/imresize.py:104-136) after
+    cropping HR to multiples of the scale as datasets/_isr.py:216-221 does.  Two golden networks, both the reference
+    BASIC_MODEL class: "x2" = the shipped trained checkpoint models/pretrained_weights/wdsr_b_x2_8_24.pt (realistic
+    ~30 dB outputs; its tensors are already in fixture G3) and "x4" = 16 blocks / 24 units at the seeded init
+    (torch.manual_seed(130); no x4 checkpoint ships).  Stored per image and network: LR, psnr / psnr_y of the reference
+    output against HR (utils/estimate.py:123-125 shaves), output mean / mean-abs, and a 4 x 4-strided sample of the
+    output (the full outputs would be 18 MB); HR is re-created from its seed by the tests (`set5_like_hr`, checksum
+    stored), the x4 weights from theirs (checksum stored)."""
+    sys.path.insert(0, os.path.join(REF, "third_party", "matlab_imresize"))
+    from imresize import imresize
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import wdsr_oracle as O
+    nets = {}
+    m2 = BASIC_MODEL(_params(num_blocks=8, num_residual_units=24, scale=2)).eval()
+    m2.load_state_dict(torch.load(os.path.join(REF, "models", "pretrained_weights", "wdsr_b_x2_8_24.pt"), map_location="cpu",
+                                  weights_only=True), strict=True)
+    nets["x2"] = (m2, 2)
+    torch.manual_seed(130)
+    nets["x4"] = (BASIC_MODEL(_params(num_blocks=16, num_residual_units=24, scale=4)).eval(), 4)
+    d = {"x4_weight_sum": np.float64(sum(v.double().sum().item() for v in nets["x4"][0].state_dict().values())),
+         "x4_weight_abs": np.float64(sum(v.double().abs().sum().item() for v in nets["x4"][0].state_dict().values()))}
+    for tag, (m, r) in nets.items():
+        for i, hw in enumerate(SET5_SHAPES):
+            hr = set5_like_hr(i, hw)
+            h, w = hw
+            hr = hr[:, :h - h % r, :w - w % r]
+            lr = imresize(hr.permute(1, 2, 0).double().numpy(), scalar_scale=1.0 / r)
+            lr_t = torch.from_numpy(lr).permute(2, 0, 1)[None].half().float()         # stored (and consumed) at fp16 precision
+            with torch.no_grad():
+                sr = m(lr_t)
+            k = f"{tag}_{i}"
+            d["lr_" + k] = lr_t.half().numpy()
+            d["sr_sample_" + k] = _np(sr[..., ::4, ::4])
+            d["sr_mean_" + k] = np.float64(sr.double().mean().item())
+            d["sr_abs_" + k] = np.float64(sr.double().abs().mean().item())
+            d["psnr_" + k] = np.float64(O.psnr(sr, hr[None], shave=r + 6).item())         # utils/estimate.py:123: shave = scale + 6
+            d["psnr_y_" + k] = np.float64(O.psnr_y(sr, hr[None], shave=r).item())         # :125: shave = scale
+            if tag == "x2":
+                d[f"hr_sum_{i}"] = np.float64(hr.double().sum().item())
+            print(f"G13 {tag} image {i} {tuple(hr.shape)}: psnr {d['psnr_' + k]:.4f} psnr_y {d['psnr_y_' + k]:.4f}")
+    np.savez_compressed(os.path.join(OUT, "g13_set5_shaped.npz"), **d)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     sys.path.insert(0, REF)
@@ -248,6 +438,9 @@ def main():
     g5_rounding(ops)
     g6_split_block(wdsr_b)
     g7_g8_vsr()
+    g10_nas_model()
+    g11_g12_video_models()
+    g13_set5_shaped(BASIC_MODEL)
 
 
 if __name__ == "__main__":

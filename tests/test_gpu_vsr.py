@@ -70,9 +70,11 @@ def test_recurrent_propagation_matches_oracle():
     x = torch.rand(1, 5, 3, 64, 64, generator=g)
     fl = torch.rand(1, 4, 2, 64, 64, generator=g) * 4 - 2
     ob, of = propagate(x.cuda(), fl.cuda(), -fl.cuda(), fb.cuda(), ff.cuda(), O.flow_warp)
-    tb = lambda t: O.conv_residual_blocks_forward(t, sdb, "main")
-    tf = lambda t: O.conv_residual_blocks_forward(t, sdf, "main")
-    rb, rf = propagate(x, fl, -fl, tb, tf, O.flow_warp)
+    # reference side: the ORACLE's own restatement of the loops (oracle/wdsr_oracle.py:_propagate, pinned against the
+    # reference MotionVectorVSR / BasicVSR_origin by G11 / G12), not the product helper
+    sd = {f"backward_trunk.{k}": v for k, v in sdb.items()}
+    sd.update({f"forward_trunk.{k}": v for k, v in sdf.items()})
+    rb, rf = O._propagate(x, fl, -fl, sd, 24)
     for a, b in zip(ob + of, rb + rf):
         assert (a.cpu() - b).abs().max().item() <= 2e-5 * b.abs().max().item()
 
@@ -109,8 +111,9 @@ def test_recurrent_propagation_all_hip():
     x = torch.rand(2, 3, 3, 40, 36, generator=g)
     fl = torch.rand(2, 2, 2, 40, 36, generator=g) * 4 - 2
     ob, of = propagate(x.cuda(), fl.cuda(), -fl.cuda(), fb.cuda(), ff.cuda(), flow_warp)
-    rb, rf = propagate(x, fl, -fl, lambda t: O.conv_residual_blocks_forward(t, sdb, "main"),
-                       lambda t: O.conv_residual_blocks_forward(t, sdf, "main"), O.flow_warp)
+    sd = {f"backward_trunk.{k}": v for k, v in sdb.items()}
+    sd.update({f"forward_trunk.{k}": v for k, v in sdf.items()})
+    rb, rf = O._propagate(x, fl, -fl, sd, 24)                # the oracle's loops (pinned by G11 / G12), not the product's
     for a, b in zip(ob + of, rb + rf):
         assert (a.cpu() - b).abs().max().item() <= 5e-5 * b.abs().max().item()
 

@@ -163,3 +163,111 @@ def test_g9_psnr_hand_cases():
     assert float(O.psnr_y(torch.cat([hr + e] * 3), torch.cat([hr] * 3), shave=2)) == pytest.approx(3 * exp_y, abs=3e-3)
     # clamp to [0,1] before the difference
     assert float(O.psnr_y(torch.full_like(hr, 1.5), torch.ones_like(hr) - e, shave=0)) == pytest.approx(exp_y, abs=1e-3)
+
+
+# ---- G10: the whole reference NAS_MODEL pins the oracle's model-level glue ----
+def test_g10_nas_model_glue_matches_reference(golden_dir):
+    d = _load(golden_dir, "g10_nas_model.npz")
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in _sd(d).items()}
+    out, speed = O.nas_model_forward(d["x"], sd, 4, 0.5, training=True)
+    _close(out, d["out_train"])
+    _close(speed, d["speed_train"], rel=1e-6)
+    ori, tgt = float(d["ori_speed"]), float(d["speed_target"])
+    l1 = torch.nn.functional.l1_loss(out, d["hr"])
+    ls = O.speed_loss(speed, tgt, ori - tgt, 0.1)
+    torch.testing.assert_close(l1, d["loss_l1"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(ls, d["loss_speed"], rtol=1e-6, atol=1e-7)
+    (l1 + ls).backward()
+    n_checked = 0
+    for k, p in sd.items():
+        if "g/" + k in d:
+            assert p.grad is not None, k
+            _close(p.grad, d["g/" + k], rel=2e-4, msg=k)
+            n_checked += 1
+        elif p.is_floating_point() and p.grad is not None:
+            # parameters the reference leaves without a gradient: beta (unused), beta1 / beta2 (ConditionFunction returns
+            # None for them) -- SURVEY section 9's DDP hazard
+            assert float(p.grad.abs().max()) == 0.0 or k.endswith(("beta", "beta1", "beta2")), k
+    assert n_checked == sum(1 for k in d if k.startswith("g/")) == 98
+    sd_eval = {k: v.detach().clone() for k, v in sd.items()}
+    for k in d:                                              # forward() rewrote beta1 / beta2 (wdsr_b.py:534)
+        if k.startswith("after/"):
+            sd_eval[k[len("after/"):]] = d[k]
+    oe, se = O.nas_model_forward(d["x"], sd_eval, 4, 0.5, training=False)
+    _close(oe, d["out_eval"])
+    _close(se, d["speed_eval"], rel=1e-6)
+    assert list(d["block_status"].numpy()) == [0, 2, 3] and int(d["current_blocks"]) == 3
+
+
+# ---- G11 / G12: the reference video models pin the propagation loops and the upsamplers ----
+def test_g11_motion_vector_vsr_matches_reference(golden_dir):
+    d = _load(golden_dir, "g11_mvvsr.npz")
+    sd = {k: v.clone().requires_grad_(True) for k, v in _sd(d).items()}
+    x = d["x"].clone().requires_grad_(True)
+    b, n, _, h, w = x.shape
+    out, fb, ff = O.mvvsr_forward(x, sd, 4 * h, 4 * w, num_feat=20, return_feats=True)
+    _close(out, d["out"], rel=2e-5)
+    # hooks recorded the trunk outputs in CALL order: backward direction runs frames n-1 .. 0
+    _close(torch.stack(fb[::-1], 1), d["feat_backward"], rel=2e-5)
+    _close(torch.stack(ff, 1), d["feat_forward"], rel=2e-5)
+    loss = O.charbonnier(out, d["target"])
+    torch.testing.assert_close(loss, d["loss"], rtol=1e-6, atol=1e-7)
+    loss.backward()
+    _close(x.grad, d["dx"], rel=2e-4)
+    for k, p in sd.items():
+        if "g/" + k in d:
+            _close(p.grad, d["g/" + k], rel=2e-4, msg=k)
+        else:                                                # upconv1/2, conv_hr: constructed, never used (mvvsr_arch.py:99-100)
+            assert p.grad is None, k
+
+
+def test_g12_basicvsr_origin_matches_reference(golden_dir):
+    d = _load(golden_dir, "g12_basicvsr_origin.npz")
+    sd = {k: v.clone().requires_grad_(True) for k, v in _sd(d).items()}
+    x = d["x"].clone().requires_grad_(True)
+    b, n, _, h, w = x.shape
+    out = O.basicvsr_origin_forward(x, d["flows_forward"], d["flows_backward"], sd, 4 * h, 4 * w, num_feat=24)
+    _close(out, d["out"], rel=2e-5)
+    loss = O.charbonnier(out, d["target"])
+    torch.testing.assert_close(loss, d["loss"], rtol=1e-6, atol=1e-7)
+    loss.backward()
+    _close(x.grad, d["dx"], rel=2e-4)
+    for k, p in sd.items():
+        _close(p.grad, d["g/" + k], rel=2e-4, msg=k)
+
+
+# ---- G13: Set5-shaped synthetic images: the oracle reproduces the reference's outputs and PSNRs ----
+def _g13_net(tag, golden_dir):
+    if tag == "x2":
+        g3 = _load(golden_dir, "g3_pretrained_x2_8_24.npz")
+        ns = argparse.Namespace(image_mean=0.5, num_channels=3, scale=2, num_blocks=8, num_residual_units=24)
+        m = O.OracleBasicModel(ns).eval()
+        m.load_state_dict(_sd(g3), strict=True)
+        return m, 2
+    torch.manual_seed(130)
+    ns = argparse.Namespace(image_mean=0.5, num_channels=3, scale=4, num_blocks=16, num_residual_units=24)
+    return O.OracleBasicModel(ns).eval(), 4
+
+
+@pytest.mark.parametrize("tag", ["x2", "x4"])
+def test_g13_set5_shaped_outputs_and_psnr(golden_dir, tag):
+    from oracle.set5_like import SET5_SHAPES, set5_like_hr
+    d = _load(golden_dir, "g13_set5_shaped.npz")
+    m, r = _g13_net(tag, golden_dir)
+    if tag == "x4":                                          # the seeded init IS the reference's (same draws, same order)
+        ws = sum(v.double().sum().item() for v in m.state_dict().values())
+        assert abs(ws - float(d["x4_weight_sum"])) <= 1e-9 * float(d["x4_weight_abs"])
+    for i, hw in enumerate(SET5_SHAPES if tag == "x2" else SET5_SHAPES[1:3]):       # (x4 at 16 blocks: two images keep the CPU suite short)
+        if tag == "x4":
+            i += 1
+        hr = set5_like_hr(i, hw)
+        hr = hr[:, :hw[0] - hw[0] % r, :hw[1] - hw[1] % r]
+        if tag == "x2":
+            assert abs(hr.double().sum().item() - float(d[f"hr_sum_{i}"])) <= 1e-6 * float(d[f"hr_sum_{i}"])
+        k = f"{tag}_{i}"
+        with torch.no_grad():
+            sr = m(d["lr_" + k].float())
+        _close(sr[..., ::4, ::4], d["sr_sample_" + k], rel=2e-5)
+        assert abs(sr.double().mean().item() - float(d["sr_mean_" + k])) <= 2e-6
+        assert abs(O.psnr(sr, hr[None], shave=r + 6).item() - float(d["psnr_" + k])) <= 1e-3
+        assert abs(O.psnr_y(sr, hr[None], shave=r).item() - float(d["psnr_y_" + k])) <= 1e-3
