@@ -33,9 +33,9 @@ HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E 8.
 BATCH, LR, SCALE, BLOCKS, UNITS = 32, 48, 4, 16, 24
 
 
-def model_ns(dtype="bf16"):
+def model_ns(dtype="bf16", segments=1):
     return argparse.Namespace(model_type="BASIC_MODEL", image_mean=0.5, num_channels=3, scale=SCALE,
-                              num_blocks=BLOCKS, num_residual_units=UNITS, hot_dtype=dtype)
+                              num_blocks=BLOCKS, num_residual_units=UNITS, hot_dtype=dtype, hot_grad_segments=segments)
 
 
 def algorithmic_bytes(n, h, w, f, nb, r, s):
@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ddp-wrapper", action="store_true",
+                    help="N > 1: train through torch's DistributedDataParallel wrapper instead of model.train_step's own all-reduce")
     ap.add_argument("--force-ddp", action="store_true",
                     help="wrap in DistributedDataParallel even with one rank (measures the DDP/RCCL overhead on one GPU)")
     args = ap.parse_args()
@@ -130,11 +132,19 @@ def main():
     from mobilesuperresolution_amd.models import get_model
 
     torch.manual_seed(0)                                # identical replicas (DDP broadcasts rank 0 anyway)
-    model = get_model(model_ns(args.dtype)).to(dev).train()
+    # Data parallel.  Default: `model.train_step(..., process_group)` -- the fused step with the gradient all-reduce (RCCL,
+    # average) in two halves, the first running under the early half of the backward.  --ddp-wrapper: the reference's own
+    # DistributedDataParallel wrapper (pretrain.py:239) over the two-segment parameter mode (two autograd nodes, one
+    # bucket each: the same overlap through DDP's hooks), with torch's loss and optimizer.
+    wrapper = use_ddp and args.ddp_wrapper
+    model = get_model(model_ns(args.dtype, 2 if wrapper else 1)).to(dev).train()
     net = model
-    if use_ddp:
+    if wrapper:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
-                                                        gradient_as_bucket_view=True, broadcast_buffers=False)
+                                                        gradient_as_bucket_view=True, broadcast_buffers=False,
+                                                        bucket_cap_mb=model.ddp_bucket_cap_mb())
+    elif use_ddp:
+        dist.broadcast(model.flat.data, src=0)              # identical replicas, as DDP's constructor guarantees
     lr_rate = 1e-3 * world                              # pretrain.py:216 linear scaling
     try:
         opt = torch.optim.Adam(model.parameters(), lr=lr_rate, fused=True)
@@ -152,11 +162,13 @@ def main():
         opt.step()
         return loss
 
-    fused = not use_ddp                                  # one rank: the whole step is one call into the library
+    fused = not wrapper                                  # the library's own step (one rank: one call; N ranks: + 2 all-reduces)
     state = model.make_train_state(lr=lr_rate) if fused else None
 
+    pg = dist.group.WORLD if (use_ddp and fused) else None   # --force-ddp on one rank: the data-parallel route all the same
+
     def step():
-        return model.train_step(x, hr, state) if fused else step_unfused()
+        return model.train_step(x, hr, state, process_group=pg) if fused else step_unfused()
 
     def sync():
         if use_ddp:
@@ -199,7 +211,7 @@ def main():
     dist_ms = per_step_ms(step, nd)
     item_ms = wall_ms(lambda: step().item(), nd)
     unfused_ms = None
-    if fused:
+    if fused and not use_ddp:
         for _ in range(5):                               # (torch's optimizer initialises its state on first use)
             step_unfused()
         unfused_ms = wall_ms(step_unfused, nd)
@@ -224,7 +236,7 @@ def main():
     if rank == 0:
         L.set_timer(timer)
     for _ in range(5):
-        step_unfused()
+        step_unfused() if not (use_ddp and fused) else step()
     L.set_timer(None)
     sync()
 
@@ -287,8 +299,10 @@ def main():
             "value": round(world * BATCH * HR_MPIX_PER_PATCH * args.steps / elapsed, 2),
             "unit": "HR-Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "step_route": "model.train_step: loss folded into the tail backward + Adam kernel, one C call" if fused
-                          else "DistributedDataParallel: forward / F.l1_loss / backward + all-reduce / torch Adam",
+            "step_route": ("model.train_step: loss folded into the tail backward + Adam kernel" +
+                           (", gradient all-reduce (RCCL avg) in two halves overlapped with the backward" if use_ddp else ", one C call"))
+                          if fused else "DistributedDataParallel wrapper (two gradient segments): forward / F.l1_loss / backward + "
+                                        "bucketed all-reduce / torch Adam",
             "per_step_ms": {"n": nd, "median": round(dist_ms[nd // 2], 4), "p10": round(dist_ms[nd // 10], 4),
                             "p90": round(dist_ms[(nd * 9) // 10], 4)},
             "ms_per_step_with_item_sync": round(item_ms, 4),

@@ -226,6 +226,9 @@ typedef struct {
    * the L1 (loss_kind 1, pretrain.py:73) or Charbonnier (2, train_video_superresolution.py:43-53) gradient on the
    * fly, loss_gscale = upstream gradient / numel; loss_part[wgs_tail] receives the per-workgroup loss sums */
   const float* hr; int loss_kind; float loss_gscale; float* loss_part;
+  /* optional two-part backward (sr_wdsr_net_backward_part): first block of the late half, and the rows of chan_tab /
+   * bias_tab where the late parameters (body[nb_split..], tail, skip) begin */
+  int nb_split, chan_split, bias_split;
 } sr_wdsr_net_t;
 
 /* weight-norm + packing + head + NB fused blocks + fused tail.  flags: SR_NET_SAVE_ACTS keeps every block input
@@ -238,6 +241,10 @@ typedef struct {
 int sr_wdsr_net_forward(const sr_wdsr_net_t* net, int flags, sr_stream_t stream);
 /* full backward: d(loss)/d(out) -> gflat (gradient of every parameter in the flat buffer). */
 int sr_wdsr_net_backward(const sr_wdsr_net_t* net, sr_stream_t stream);
+/* The same in two parts, so that a data-parallel trainer can all-reduce the late parameters' gradient while the early
+ * half of the backward still runs (pretrain.py:239 DDP overlap): part 1 = tail + blocks [nb_split, NB) (their entries
+ * of gflat are final on return), part 2 = blocks [0, nb_split) + head; part 0 = everything. */
+int sr_wdsr_net_backward_part(const sr_wdsr_net_t* net, int part, sr_stream_t stream);
 
 /* Standalone nn.PixelShuffle(r) (models/basic_wdsr_b.py:80-83; basicvsr_arch_origin.py:37,87-88), NCHW fp32, bit-exact:
  * out[n, c, h r + i, w r + j] = in[n, c r^2 + i r + j, h, w].  C = channels of the shuffled tensor, H x W = size before

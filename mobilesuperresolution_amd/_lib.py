@@ -59,6 +59,7 @@ SIGNATURES = {
     "sr_wdsr_net_train_step": ([_P, _P, _P, _L, _P, _F, _P, _P], _I),
     "sr_wdsr_net_forward": ([_P, _I, _P], _I),
     "sr_wdsr_net_backward": ([_P, _P], _I),
+    "sr_wdsr_net_backward_part": ([_P, _I, _P], _I),
     "sr_probe_mfma_bf16": ([_P, _P, _P, _P], _I),
     "sr_probe_mfma_f32": ([_P, _P, _P, _P], _I),
     "sr_probe_tr_read": ([_P, _I, _P, _P, _P], _I),
@@ -80,7 +81,8 @@ class WdsrNet(ctypes.Structure):
         [("ga_sidx", _P), ("ga_dst", _P), ("n_ga", _I), ("gb_sidx", _P), ("gb_dst", _P), ("n_gb", _I),
          ("gt_sidx", _P), ("gt_dst", _P), ("n_gt", _I), ("gh_sidx", _P), ("gh_dst", _P), ("n_gh", _I),
          ("x", _P), ("acts", _P), ("grads", _P), ("out", _P), ("dout", _P), ("tsave", _P), ("dtsave", _P),
-         ("hr", _P), ("loss_kind", _I), ("loss_gscale", _F), ("loss_part", _P)])
+         ("hr", _P), ("loss_kind", _I), ("loss_gscale", _F), ("loss_part", _P),
+         ("nb_split", _I), ("chan_split", _I), ("bias_split", _I)])
 
 
 class AdamScalars(ctypes.Structure):

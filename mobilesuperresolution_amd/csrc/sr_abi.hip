@@ -699,9 +699,12 @@ extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int flags, sr_stream_
   return sr_tail_fwd(cur, n->x, n->out, n->blob_tail, n->mean, n->N, n->H, n->W, n->F, n->R, n->dtype, stream);
 }
 
-extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) {
-  if (!n || !n->flat || !n->gflat || !n->dsrc || !n->x || !n->acts || !n->grads) return -2;
-  if (n->hr ? (!n->out || !n->loss_part || (n->loss_kind != 1 && n->loss_kind != 2)) : !n->dout) return -2;
+// Backward in up to two parts so that the gradient of the LATE parameters (blocks [nb_split, NB), tail, skip) is final --
+// bucket-ready for a DistributedDataParallel all-reduce -- before the early half (head, blocks [0, nb_split)) runs.
+//   part 0: everything (one call);  part 1: late half;  part 2: early half (after part 1).
+extern "C" int sr_wdsr_net_backward_part(const sr_wdsr_net_t* n, int part, sr_stream_t stream) {
+  if (!n || !n->flat || !n->gflat || !n->dsrc || !n->x || !n->acts || !n->grads || part < 0 || part > 2) return -2;
+  if (part != 2 && (n->hr ? (!n->out || !n->loss_part || (n->loss_kind != 1 && n->loss_kind != 2)) : !n->dout)) return -2;
   hipStream_t st = (hipStream_t)stream;
   const size_t esz = n->dtype == SR_DTYPE_BF16 ? 2 : 4;
   const size_t act = (size_t)n->N * n->H * n->W * n->F * esz;
@@ -709,29 +712,34 @@ extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) 
   const long act_e = (long)n->N * n->H * n->W * n->F;
   char* acts = (char*)n->acts;
   char* grads = (char*)n->grads;
-  int rc;
-  if (n->hr) {                                      // loss folded into the tail backward: no HR gradient tensor
-    if ((rc = sr_tail_bwd_loss(n->out, n->hr, n->loss_kind, n->loss_gscale, n->loss_part, acts + (size_t)n->NB * act, n->x, n->mean,
-                               n->blob_tail, grads + (size_t)n->NB * act, n->part_tail, n->wgs_tail, n->N, n->H, n->W, n->F, n->R,
-                               n->dtype, stream)))
-      return rc;
-  } else if (n->dtype == SR_DTYPE_BF16) {           // data + weight gradients of the tail in one launch
-    if ((rc = sr_tail_bwd(n->dout, acts + (size_t)n->NB * act, n->x, n->mean, n->blob_tail, grads + (size_t)n->NB * act,
-                          n->part_tail, n->wgs_tail, n->N, n->H, n->W, n->F, n->R, n->dtype, stream)))
-      return rc;
-  } else {
-    if ((rc = sr_tail_bwd_data(n->dout, grads + (size_t)n->NB * act, n->blob_tail, n->N, n->H, n->W, n->F, n->R,
-                               n->dtype, stream)))
-      return rc;
-    if ((rc = sr_tail_wgrad(n->dout, acts + (size_t)n->NB * act, n->x, n->mean, n->part_tail, n->wgs_tail, n->N, n->H,
-                            n->W, n->F, n->R, n->dtype, stream)))
-      return rc;
-  }
   const bool pairs = net_uses_pairs(n);
   const bool saved = net_saves_side_images(n, true);
   const size_t side = side_image_bytes(n);
-  for (int i = n->NB - 1; i >= 0; --i) {
-    if (pairs && i >= 1) {
+  int split = part == 0 ? 0 : n->nb_split;
+  if (part != 0 && (split <= 0 || split >= n->NB || (pairs && ((n->NB - split) & 1)))) return -2;   // (pair launches must not straddle the split)
+  const int b0 = part == 1 ? split : 0, b1 = part == 2 ? split : n->NB;      // blocks [b0, b1) handled by this call
+  int rc;
+  if (part != 2) {
+    if (n->hr) {                                    // loss folded into the tail backward: no HR gradient tensor
+      if ((rc = sr_tail_bwd_loss(n->out, n->hr, n->loss_kind, n->loss_gscale, n->loss_part, acts + (size_t)n->NB * act, n->x,
+                                 n->mean, n->blob_tail, grads + (size_t)n->NB * act, n->part_tail, n->wgs_tail, n->N, n->H, n->W,
+                                 n->F, n->R, n->dtype, stream)))
+        return rc;
+    } else if (n->dtype == SR_DTYPE_BF16) {         // data + weight gradients of the tail in one launch
+      if ((rc = sr_tail_bwd(n->dout, acts + (size_t)n->NB * act, n->x, n->mean, n->blob_tail, grads + (size_t)n->NB * act,
+                            n->part_tail, n->wgs_tail, n->N, n->H, n->W, n->F, n->R, n->dtype, stream)))
+        return rc;
+    } else {
+      if ((rc = sr_tail_bwd_data(n->dout, grads + (size_t)n->NB * act, n->blob_tail, n->N, n->H, n->W, n->F, n->R,
+                                 n->dtype, stream)))
+        return rc;
+      if ((rc = sr_tail_wgrad(n->dout, acts + (size_t)n->NB * act, n->x, n->mean, n->part_tail, n->wgs_tail, n->N, n->H,
+                              n->W, n->F, n->R, n->dtype, stream)))
+        return rc;
+    }
+  }
+  for (int i = b1 - 1; i >= b0; --i) {
+    if (pairs && i >= b0 + 1) {
       if ((rc = sr_wdsr_block2_bwd_data(acts + (size_t)(i - 1) * act, acts + (size_t)i * act, grads + (size_t)(i + 1) * act,
                                         grads + (size_t)i * act, grads + (size_t)(i - 1) * act,
                                         (char*)n->blob_body + (i - 1) * blob, (char*)n->blob_body + i * blob,
@@ -760,39 +768,59 @@ extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) 
                                             n->N, n->H, n->W, n->F, n->dtype, stream)))
       return rc;
   }
-  if (saved) {
-    if ((rc = sr_wdsr_block_wgrad_saved(acts, grads + act, n->tsave, n->dtsave, n->blob_body, n->cinit_body, n->part_a,
-                                        n->part_b, n->NB, n->wgs_body, n->N, n->H, n->W, n->F, n->dtype, act_e, act_e,
-                                        (long)(side / esz), (long)n->n_idx_body, (long)n->n_idx_cinit, stream)))
+  // weight gradients of blocks [b0, b1): every per-layer pointer advanced by b0 layers
+  const int nl = b1 - b0;
+  const int wgs_part = nl > 0 ? (n->wgs_body * n->NB) / nl : 0;
+  if (nl > 0) {
+    char* a0 = acts + (size_t)b0 * act;
+    char* g1 = grads + (size_t)(b0 + 1) * act;
+    char* wb0 = (char*)n->blob_body + (size_t)b0 * blob;
+    const float* ci0 = n->cinit_body + (size_t)b0 * n->n_idx_cinit;
+    float* pa0 = n->part_a;                         // a part owns the whole partial-slab buffer while it runs, so a
+    float* pb0 = n->part_b;                         // half-depth part spreads each layer over twice the workgroups
+    if (saved) {
+      if ((rc = sr_wdsr_block_wgrad_saved(a0, g1, (char*)n->tsave + (size_t)b0 * side, (char*)n->dtsave + (size_t)b0 * side, wb0, ci0,
+                                          pa0, pb0, nl, wgs_part, n->N, n->H, n->W, n->F, n->dtype, act_e, act_e,
+                                          (long)(side / esz), (long)n->n_idx_body, (long)n->n_idx_cinit, stream)))
+        return rc;
+    } else if ((rc = sr_wdsr_block_wgrad(a0, g1, wb0, ci0, pa0, pb0, nl, wgs_part, n->N, n->H, n->W, n->F, n->dtype, act_e,
+                                         act_e, (long)n->n_idx_body, (long)n->n_idx_cinit, stream)))
       return rc;
-  } else if ((rc = sr_wdsr_block_wgrad(acts, grads + act, n->blob_body, n->cinit_body, n->part_a, n->part_b, n->NB,
-                                       n->wgs_body, n->N, n->H, n->W, n->F, n->dtype, act_e, act_e, (long)n->n_idx_body,
-                                       (long)n->n_idx_cinit, stream)))
-    return rc;
-  if ((rc = sr_head_wgrad(grads, n->x, n->mean, n->part_head, n->wgs_head, n->N, n->H, n->W, n->F, n->dtype, stream)))
-    return rc;
-  // slabs -> d(effective weights) -> d(flat parameters)
+  }
+  if (part != 1)
+    if ((rc = sr_head_wgrad(grads, n->x, n->mean, n->part_head, n->wgs_head, n->N, n->H, n->W, n->F, n->dtype, stream)))
+      return rc;
+  // slabs -> d(effective weights) -> d(flat parameters), for the layers of this part
   {
     UnpackSegs us;
-    us.nseg = 4;
+    us.nseg = 0;
     int blk = 0;
-    auto add = [&](int k, const float* part, const int* sidx, const int* dst, long off, long stride, long slab, int wgs,
-                   int cnt, int reps) {
-      us.s[k] = UnpackSeg{part, sidx, dst, off, stride, slab, wgs, cnt, reps, blk};
+    auto add = [&](const float* part_, const int* sidx, const int* dst, long off, long stride, long slab, int wgs, int cnt,
+                   int reps) {
+      us.s[us.nseg++] = UnpackSeg{part_, sidx, dst, off, stride, slab, wgs, cnt, reps, blk};
       blk += reps * ((cnt + 63) / 64);
     };
-    add(0, n->part_a, n->ga_sidx, n->ga_dst, n->src_body_off, n->src_body_stride, n->slab_a, n->wgs_body, n->n_ga, n->NB);
-    add(1, n->part_b, n->gb_sidx, n->gb_dst, n->src_body_off, n->src_body_stride, n->slab_b, n->wgs_body, n->n_gb, n->NB);
-    add(2, n->part_tail, n->gt_sidx, n->gt_dst, n->src_tail_off, 0, n->slab_tail, n->wgs_tail, n->n_gt, 1);
-    add(3, n->part_head, n->gh_sidx, n->gh_dst, n->src_head_off, 0, n->slab_head, n->wgs_head, n->n_gh, 1);
+    if (nl > 0) {
+      add(n->part_a, n->ga_sidx, n->ga_dst, n->src_body_off + b0 * n->src_body_stride, n->src_body_stride, n->slab_a, wgs_part,
+          n->n_ga, nl);
+      add(n->part_b, n->gb_sidx, n->gb_dst, n->src_body_off + b0 * n->src_body_stride, n->src_body_stride, n->slab_b, wgs_part,
+          n->n_gb, nl);
+    }
+    if (part != 2) add(n->part_tail, n->gt_sidx, n->gt_dst, n->src_tail_off, 0, n->slab_tail, n->wgs_tail, n->n_gt, 1);
+    if (part != 1) add(n->part_head, n->gh_sidx, n->gh_dst, n->src_head_off, 0, n->slab_head, n->wgs_head, n->n_gh, 1);
     hipLaunchKernelGGL(unpack_all_kernel, dim3(blk), dim3(256), 0, st, n->dsrc, us);
   }
-  const int cb = (n->n_chan + 3) / 4, bb = (n->n_bias + 255) / 256;
-  hipLaunchKernelGGL(wn_bwd_kernel, dim3(cb + bb), dim3(256), 0, st, n->flat, n->dsrc, n->gflat,
-                     (const int4*)n->chan_tab, n->n_chan, n->bias_tab, n->n_bias, cb);
+  // weight-norm backward over the table rows of this part (rows are in state_dict order: head, body.0 .., tail, skip)
+  const int c0 = part == 1 ? n->chan_split : 0, c1 = part == 2 ? n->chan_split : n->n_chan;
+  const int d0 = part == 1 ? n->bias_split : 0, d1 = part == 2 ? n->bias_split : n->n_bias;
+  const int cb = (c1 - c0 + 3) / 4, bb = (d1 - d0 + 255) / 256;
+  hipLaunchKernelGGL(wn_bwd_kernel, dim3(cb + bb), dim3(256), 0, st, n->flat, n->dsrc, n->gflat, (const int4*)n->chan_tab + c0,
+                     c1 - c0, n->bias_tab + 3 * d0, d1 - d0, cb);
   SR_HIP_CHECK_LAUNCH();
   return 0;
 }
+
+extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) { return sr_wdsr_net_backward_part(n, 0, stream); }
 
 // ------------------------------------------------------------------------------------------
 // standalone PixelShuffle

@@ -130,6 +130,15 @@ class WDSRLayout:
         self.slab_tail, self.slab_head = ge["tail_size"], ge["head_size"]
 
 
+    def split_at(self, nb_split: int):
+        """Where the late half (body[nb_split ..], tail, skip) begins: (offset in the flat parameter, row of chan_tab,
+        row of bias_tab).  The flat layout and both tables are in state_dict order (head, body.0 .., tail, skip)."""
+        per_block = sum(c.cout for c in self.convs if c.name.startswith("body.0."))
+        head_rows = next(c.cout for c in self.convs if c.name == "head")
+        first = min(off for name, (off, _) in self.entries.items() if name.startswith(f"body.{nb_split}."))
+        return first, head_rows + nb_split * per_block, head_rows + nb_split * per_block
+
+
 @lru_cache(maxsize=None)
 def get_layout(F: int, NB: int, R: int) -> WDSRLayout:
     return WDSRLayout(F, NB, R)

@@ -90,6 +90,9 @@ class _DeviceState:
             setattr(n, k + "_dst", self.g[k][1].data_ptr())
             setattr(n, "n_" + k, self.g[k][0].numel())
         n.loss_part = self.loss_part.data_ptr()
+        if model.nb_split:
+            _, n.chan_split, n.bias_split = lay.split_at(model.nb_split)
+            n.nb_split = model.nb_split
         self.net = n
 
     def call_struct(self) -> "L.WdsrNet":
@@ -116,8 +119,43 @@ class BASIC_MODEL(nn.Module):
         self.hot_dtype = _hot_dtype(params)
         self.wgs_body = int(getattr(params, "hot_wgs_body", os.environ.get("SR_WGS_BODY", 16)))
         self.layout = get_layout(f, nb, self.scale)
-        self.flat = nn.Parameter(self._reference_init())
+        # Data-parallel training: `hot_grad_segments = 2` (or SR_GRAD_SEGMENTS=2) exposes the flat buffer as TWO parameters,
+        # `flat_lo` (head, body[0 .. NB/2)) and `flat_hi` (body[NB/2 ..], tail, skip), views of one storage, and runs
+        # backward as two autograd nodes: the gradient of `flat_hi` is final after the first one, so DistributedDataParallel
+        # (pretrain.py:239) all-reduces it while the early half of the backward still runs.  Default 1: one parameter.
+        self.grad_segments = int(getattr(params, "hot_grad_segments", None) or os.environ.get("SR_GRAD_SEGMENTS", 1))
+        if self.grad_segments not in (1, 2):
+            raise NotImplementedError("hot_grad_segments must be 1 or 2")
+        init = self._reference_init()
+        # first block of the "late half" of a two-part backward (an even number of blocks: pair launches must not straddle it)
+        self.nb_split = nb - 2 * ((nb // 2 + 1) // 2) if nb >= 2 else 0
+        if self.grad_segments == 2 and nb >= 2:
+            k = self.layout.split_at(self.nb_split)[0]
+            self.flat_lo = nn.Parameter(init[:k])
+            self.flat_hi = nn.Parameter(init[k:])
+            self._flat_master = init                           # plain attribute: the storage both parameters view
+        else:
+            self.grad_segments = 1
+            self.flat = nn.Parameter(init)
         self._dev = {}
+
+    def __getattr__(self, name):
+        if name == "flat" and "_flat_master" in self.__dict__:    # two-segment mode: the whole buffer (not a Parameter)
+            return self.__dict__["_flat_master"]
+        return super().__getattr__(name)
+
+    def _apply(self, fn, recurse=True):
+        if self.grad_segments == 2:                          # keep both parameters views of ONE storage across .cuda() / .to()
+            with torch.no_grad():
+                master = fn(self._flat_master)
+            k = self.flat_lo.numel()
+            self.flat_lo.data, self.flat_hi.data = master[:k], master[k:]
+            for p in (self.flat_lo, self.flat_hi):
+                if p.grad is not None:
+                    p.grad.data = fn(p.grad.data)
+            self._flat_master = master
+            return self
+        return super()._apply(fn, recurse)
 
     # ---- the per-device state holds ctypes pointers and device work buffers: never pickled or deep-copied (the reference
     # trainers pickle whole modules, train_video_superresolution.py:306; EMA / best-model copies use deepcopy) ----
@@ -133,7 +171,17 @@ class BASIC_MODEL(nn.Module):
         memo[id(self)] = new
         for k, v in self.__dict__.items():
             new.__dict__[k] = {} if k == "_dev" else copy.deepcopy(v, memo)
+        if new.grad_segments == 2:                           # deepcopy cloned the three tensors separately: re-tie the views
+            k = new.flat_lo.numel()
+            new.flat_lo.data, new.flat_hi.data = new._flat_master[:k], new._flat_master[k:]
         return new
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        if self.grad_segments == 2:
+            k = self.flat_lo.numel()
+            self._flat_master = torch.cat([self.flat_lo.detach(), self.flat_hi.detach()])
+            self.flat_lo.data, self.flat_hi.data = self._flat_master[:k], self._flat_master[k:]
 
     # ---- initial values exactly as the reference constructs them (same RNG draws, same constants) ----
     def _reference_init(self) -> torch.Tensor:
@@ -180,7 +228,7 @@ class BASIC_MODEL(nn.Module):
                 view.copy_(src)
         known = {prefix + n for n in self.layout.entries}
         for key in state_dict:
-            if key.startswith(prefix) and key not in known and key != prefix + "flat":
+            if key.startswith(prefix) and key not in known and key not in (prefix + "flat", prefix + "flat_lo", prefix + "flat_hi"):
                 unexpected_keys.append(key)
 
     # ---- execution ----
@@ -242,6 +290,12 @@ class BASIC_MODEL(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._check_input(x)
         x = x.contiguous().float()
+        if self.grad_segments == 2:
+            if torch.is_grad_enabled() and (self.flat_lo.requires_grad or self.flat_hi.requires_grad):
+                shared = _Shared()
+                token = _NetLoFunction.apply(x, self.flat_lo, self, shared)
+                return _NetHiFunction.apply(token, self.flat_hi, self, shared)
+            return self._forward_impl(x, self.flat.detach(), False)[0]
         if torch.is_grad_enabled() and self.flat.requires_grad:
             return _NetFunction.apply(x, self.flat, self)
         return self._forward_impl(x, self.flat.detach(), False)[0]
@@ -286,16 +340,33 @@ class BASIC_MODEL(nn.Module):
         eps 1e-12) as a differentiable scalar: `model.loss(lr, hr).backward()` fills `flat.grad` exactly like
         `F.l1_loss(model(lr), hr).backward()`, but the loss gradient is formed inside the tail backward kernel."""
         x, hr = self._check_target(x, hr)
+        if self.grad_segments == 2:
+            raise NotImplementedError("model.loss() is the one-parameter route; with hot_grad_segments = 2 use forward() + a torch "
+                                      "loss (DistributedDataParallel hooks need the two gradient nodes)")
         return _NetLossFunction.apply(x, hr, self.flat, self, kind, float(weight))
+
+    def ddp_bucket_cap_mb(self) -> float:
+        """`bucket_cap_mb` for DistributedDataParallel such that each gradient segment is its own bucket (two-segment
+        mode): DDP closes a bucket once it has reached the cap, so the cap is half the smaller segment."""
+        if self.grad_segments != 2:
+            return 25.0
+        return 0.5 * min(self.flat_lo.numel(), self.flat_hi.numel()) * 4 / (1 << 20)
 
     def make_train_state(self, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
         """Adam state for train_step (pretrain.py:137 hyper-parameters by default); `state.lr` may be changed between
         steps (MultiStepLR, pretrain.py:139-142)."""
         return AdamState(self.flat, lr, betas, eps)
 
-    def train_step(self, x: torch.Tensor, hr: torch.Tensor, state: "AdamState", kind: str = "l1", weight: float = 1.0):
+    def train_step(self, x: torch.Tensor, hr: torch.Tensor, state: "AdamState", kind: str = "l1", weight: float = 1.0,
+                   process_group=None):
         """One whole training step -- forward, loss, backward, Adam -- in ONE call into libsr_hotpath.so; `flat` is updated
-        in place.  Returns the loss as a device scalar (no host sync; `.item()` it when pretrain.py:82 would)."""
+        in place.  Returns the loss as a device scalar (no host sync; `.item()` it when pretrain.py:82 would).
+
+        Data parallel (`process_group`, or the default group when torch.distributed is initialised with more than one
+        rank): what DistributedDataParallel does for pretrain.py:239, as three calls -- forward + the LATE half of the
+        backward, an asynchronous RCCL all-reduce (average) of that half's gradient, the EARLY half of the backward
+        running underneath it, the second all-reduce, then Adam on the averaged gradient.  Replicas must start equal
+        (broadcast `flat` once, as DDP's constructor does)."""
         x, hr = self._check_target(x, hr)
         if state.exp_avg.device != x.device:
             raise L.HotpathError("optimizer state and input on different devices")
@@ -303,6 +374,9 @@ class BASIC_MODEL(nn.Module):
         flat = self.flat.detach()
         lay = self.layout
         n, _, h, w = x.shape
+        if self.grad_segments == 2:
+            raise NotImplementedError("train_step is the single-GPU fused step; with hot_grad_segments = 2 train through "
+                                      "DistributedDataParallel (forward / loss / backward / optimizer)")
         acts = torch.empty((lay.NB + 1, n, h, w, lay.F), dtype=self.hot_dtype, device=x.device)
         grads = torch.empty_like(acts)
         out = torch.empty((n, 3, self.scale * h, self.scale * w), dtype=torch.float32, device=x.device)
@@ -320,10 +394,33 @@ class BASIC_MODEL(nn.Module):
         net.hr, net.loss_kind, net.loss_gscale = hr.data_ptr(), self._LOSS_KINDS[kind], self._gscale(weight, out.numel())
         loss = torch.empty((), dtype=torch.float32, device=x.device)
         scal = state.next_scalars()
+        import torch.distributed as dist
+        pg = process_group                                   # (given explicitly: the data-parallel route even on one rank)
+        if pg is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            pg = dist.group.WORLD
         with torch.cuda.device(x.device):
-            L.launch("sr_wdsr_net_train_step", L.lib().sr_wdsr_net_train_step, ctypes.byref(net), state.exp_avg.data_ptr(),
-                     state.exp_avg_sq.data_ptr(), flat.numel(), ctypes.byref(scal), float(weight) / out.numel(), loss.data_ptr(),
-                     L.stream_ptr(x.device))
+            sp = L.stream_ptr(x.device)
+            if pg is None or not self.nb_split:
+                L.launch("sr_wdsr_net_train_step", L.lib().sr_wdsr_net_train_step, ctypes.byref(net), state.exp_avg.data_ptr(),
+                         state.exp_avg_sq.data_ptr(), flat.numel(), ctypes.byref(scal), float(weight) / out.numel(),
+                         loss.data_ptr(), sp)
+            else:
+                k = lay.split_at(self.nb_split)[0]
+                lib = L.lib()
+                L.launch("sr_wdsr_net_forward", lib.sr_wdsr_net_forward, ctypes.byref(net), 1, sp)
+                L.launch("sr_wdsr_net_backward_part", lib.sr_wdsr_net_backward_part, ctypes.byref(net), 1, sp)
+                avg = dist.get_backend(pg) == "nccl"          # RCCL averages in the collective; gloo (CPU rehearsals) sums
+                op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+                h_hi = dist.all_reduce(gflat[k:], op=op, group=pg, async_op=True)     # runs under the early half
+                L.launch("sr_wdsr_net_backward_part", lib.sr_wdsr_net_backward_part, ctypes.byref(net), 2, sp)
+                h_lo = dist.all_reduce(gflat[:k], op=op, group=pg, async_op=True)
+                h_hi.wait()
+                h_lo.wait()                                   # (stream-side waits: the host does not block)
+                if not avg:
+                    gflat.div_(dist.get_world_size(pg))
+                L.launch("sr_adam_step", lib.sr_adam_step, flat.data_ptr(), gflat.data_ptr(), state.exp_avg.data_ptr(),
+                         state.exp_avg_sq.data_ptr(), flat.numel(), ctypes.byref(scal), st.loss_part.data_ptr(), st.wgs_tail,
+                         float(weight) / out.numel(), loss.data_ptr(), sp)
         _bump_version(self.flat)
         st.packed_key = None                         # the blobs no longer match `flat`
         return loss
@@ -397,6 +494,72 @@ class _NetFunction(torch.autograd.Function):
                 st.packed_key = ctx.packed_key
             L.launch("sr_wdsr_net_backward", L.lib().sr_wdsr_net_backward, ctypes.byref(net), L.stream_ptr(x.device))
         return None, gflat, None
+
+
+class _Shared:
+    """what the two autograd nodes of the two-segment mode hand each other (forward results, the gradient buffers)"""
+    __slots__ = ("out", "acts", "tsave", "dtsave", "grads", "gflat", "x", "packed_key", "net")
+
+
+class _NetLoFunction(torch.autograd.Function):
+    """early half (head, body[0 .. nb_split)).  Its forward runs the WHOLE network (one C call) and returns a token; its
+    backward is part 2 of sr_wdsr_net_backward_part and runs after _NetHiFunction's."""
+
+    @staticmethod
+    def forward(ctx, x, flat_lo, model, shared):
+        flat = model.flat.detach()
+        shared.out, shared.acts, shared.tsave = model._forward_impl(x, flat, True)
+        shared.x, shared.packed_key = x, model._state(x.device).packed_key
+        ctx.model, ctx.shared = model, shared
+        ctx.save_for_backward(flat_lo)
+        return x.new_zeros(1)
+
+    @staticmethod
+    def backward(ctx, gtoken):
+        model, sh = ctx.model, ctx.shared
+        (flat_lo,) = ctx.saved_tensors
+        x = sh.x
+        with torch.cuda.device(x.device):
+            L.launch("sr_wdsr_net_backward_part", L.lib().sr_wdsr_net_backward_part, ctypes.byref(sh.net), 2, L.stream_ptr(x.device))
+        k = flat_lo.numel()
+        return None, sh.gflat[:k], None, None
+
+
+class _NetHiFunction(torch.autograd.Function):
+    """late half (body[nb_split ..], tail, skip): backward part 1; its parameter gradient is final when it returns"""
+
+    @staticmethod
+    def forward(ctx, token, flat_hi, model, shared):
+        ctx.model, ctx.shared = model, shared
+        ctx.save_for_backward(flat_hi)
+        return shared.out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, sh = ctx.model, ctx.shared
+        (flat_hi,) = ctx.saved_tensors
+        x, acts = sh.x, sh.acts
+        st = model._state(x.device)
+        flat = model.flat.detach()
+        dout = dout.contiguous().float()
+        sh.grads = torch.empty_like(acts)
+        sh.gflat = torch.empty_like(flat)
+        sh.dtsave = torch.empty_like(sh.tsave) if sh.tsave is not None else None
+        net = st.call_struct()
+        net.N, net.H, net.W = x.shape[0], x.shape[2], x.shape[3]
+        net.flat, net.gflat, net.x = flat.data_ptr(), sh.gflat.data_ptr(), x.data_ptr()
+        net.acts, net.grads, net.dout = acts.data_ptr(), sh.grads.data_ptr(), dout.data_ptr()
+        net.tsave = sh.tsave.data_ptr() if sh.tsave is not None else None
+        net.dtsave = sh.dtsave.data_ptr() if sh.dtsave is not None else None
+        sh.net = net
+        ctx.dout = dout                                       # keep the HR gradient alive until the early half has run
+        with torch.cuda.device(x.device):
+            if st.packed_key != sh.packed_key:
+                L.launch("sr_wdsr_net_forward", L.lib().sr_wdsr_net_forward, ctypes.byref(net), 4, L.stream_ptr(x.device))
+                st.packed_key = sh.packed_key
+            L.launch("sr_wdsr_net_backward_part", L.lib().sr_wdsr_net_backward_part, ctypes.byref(net), 1, L.stream_ptr(x.device))
+        k = flat.numel() - flat_hi.numel()
+        return x.new_zeros(1), sh.gflat[k:], None, None
 
 
 class _NetLossFunction(torch.autograd.Function):
