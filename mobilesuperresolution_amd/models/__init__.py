@@ -13,7 +13,7 @@ from .spynet_arch import flow_warp
 from .wdsr_b import NAS_MODEL, ModelOutput
 
 __all__ = ["BASIC_MODEL", "NAS_MODEL", "ModelOutput", "ConvResidualBlocks", "ResidualBlockNoBN", "MotionVectorVSR",
-           "BasicVSR_origin", "flow_warp", "pixel_shuffle", "get_model", "update_argparser"]
+           "BasicVSR_origin", "flow_warp", "pixel_shuffle", "get_model", "update_argparser", "wrap_ddp"]
 
 _REGISTRY = {"BASIC_MODEL": BASIC_MODEL, "NAS_MODEL": NAS_MODEL}
 
@@ -48,3 +48,22 @@ def get_model(params):
         raise NotImplementedError(
             f"model_type {params.model_type!r} is not on the MI355X hot path (have {sorted(_REGISTRY)})")
     return cls(params)
+
+
+def wrap_ddp(model, **ddp_kwargs):
+    """`DistributedDataParallel(model, ...)` as the trainers build it (pretrain.py:239, search.py:294,332,375), plus the
+    two things the hot path needs that stock defaults do not give:
+      * BASIC_MODEL with two gradient segments: a bucket cap that separates the segments, so that the late half's
+        all-reduce runs under the early half's backward (bucket_cap_mb, gradient_as_bucket_view);
+      * NAS_MODEL: `beta`, `beta1`, `beta2` are frozen first (NAS_MODEL.freeze_gradless_parameters) -- they never receive
+        gradients and DDP without find_unused_parameters raises on them.  Freezing was chosen over
+        find_unused_parameters=True, which walks the autograd graph and synchronises with the host every iteration.
+    Call it again after each phase change of search.py:329-333,372-376 (unwrap with `.module`, length_grad / mask_grad,
+    wrap_ddp)."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    if hasattr(model, "freeze_gradless_parameters"):
+        model.freeze_gradless_parameters()
+    if isinstance(model, BASIC_MODEL) and getattr(model, "grad_segments", 1) == 2:
+        ddp_kwargs.setdefault("bucket_cap_mb", model.ddp_bucket_cap_mb())
+        ddp_kwargs.setdefault("gradient_as_bucket_view", True)
+    return DDP(model, **ddp_kwargs)

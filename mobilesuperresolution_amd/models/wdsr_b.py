@@ -447,8 +447,57 @@ class NAS_MODEL(nn.Module):
         self.skip = _WNConv(nin, nout, 5, g_init=1.0, zero_bias=True)        # bare conv in NAS_MODEL: keys skip.*
         self.shuf = nn.Sequential()
         if getattr(params, "pretrained", False):
-            raise NotImplementedError("load_pretrained (positional copy from models/pretrained_weights) is not on the hot path; "
-                                      "load a BASIC_MODEL checkpoint explicitly")
+            self.load_pretrained(getattr(params, "pretrained_path", None))
+
+    @torch.no_grad()
+    def load_pretrained(self, path=None):
+        """reference wdsr_b.py:235-250: POSITIONAL copy -- walk self.parameters() and take the checkpoint's next tensor
+        whenever the shapes agree (so a BASIC_MODEL checkpoint fills the head and nothing the search blocks own).
+        The reference reads `models/pretrained_weights/wdsr_b_x{scale}_{blocks}_{units}.pt` beside its own file; the same
+        relative location is the default here, `path` (or params.pretrained_path) names the file otherwise.  Loaded with
+        weights_only=True: nothing in the file is executed."""
+        import os
+        if path is None:
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pretrained_weights",
+                                f"wdsr_b_x{self.scale}_{self.num_blocks}_{self.num_residual_units}.pt")
+        if not os.path.isfile(path):
+            raise FileNotFoundError(f"--pretrained: no checkpoint at {path}; copy the reference's models/pretrained_weights/ "
+                                    "there or pass params.pretrained_path")
+        state_dict = torch.load(path, map_location="cpu", weights_only=True)
+        items = iter(state_dict.items())
+        try:
+            _, load_param = next(items)
+        except StopIteration:
+            return 0
+        taken = 0
+        for p in self.parameters():
+            if p.size() == load_param.size():
+                p.data = load_param.to(device=p.device, dtype=p.dtype)
+                taken += 1
+                try:
+                    _, load_param = next(items)
+                except StopIteration:
+                    pass                              # (the reference keeps comparing against the last tensor, :247-250)
+        self.__dict__.pop("_plist_cache", None)
+        return taken
+
+    def gradless_parameters(self):
+        """Parameters that are requires_grad=True in the reference yet never receive a gradient from a training forward:
+        every block's `beta` (wdsr_b.py:422, unused) and `beta1`/`beta2` (ConditionFunction.backward returns None for
+        them, :611-616; forward overwrites their .data, :534).  DistributedDataParallel without find_unused_parameters
+        raises on the second iteration when such parameters are registered (SURVEY 8, C5 hazard)."""
+        return [(f"body.{i}.{n}", getattr(m, n)) for i, m in enumerate(self.body) for n in ("beta", "beta1", "beta2")]
+
+    def freeze_gradless_parameters(self):
+        """requires_grad=False on gradless_parameters().  Training results are unchanged: the optimizer skips parameters
+        whose grad is None, and beta1/beta2 are (re)written by forward.  Call it AFTER length_grad(), which turns
+        beta1/beta2 back on (:573-577), and BEFORE wrapping in DistributedDataParallel; models.wrap_ddp does both."""
+        names = []
+        for name, p in self.gradless_parameters():
+            if p.requires_grad:
+                p.requires_grad = False
+                names.append(name)
+        return names
 
     def forward(self, x):
         if not x.is_cuda:

@@ -16,7 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--mode", default="wrapper", choices=["wrapper", "fused"])
+    ap.add_argument("--mode", default="wrapper", choices=["wrapper", "fused", "nas_phases"])
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group(os.environ.get("SR_DDP_BACKEND", "gloo"), init_method="env://")
@@ -29,6 +29,8 @@ def main():
                             hot_dtype=args.dtype, hot_grad_segments=2)
     if args.mode == "fused":
         return fused_mode(args, ns, rank, world)
+    if args.mode == "nas_phases":
+        return nas_phases_mode(args, rank, world)
     torch.manual_seed(0)
     m = get_model(ns).cuda().train()
     events = []
@@ -113,6 +115,87 @@ def fused_mode(args, ns, rank, world):
         json.dump({"replicas_equal": all(torch.equal(gathered[0], t) for t in gathered[1:]),
                    "param_err": (mine - rf).abs().max().item(), "param_scale": rf.abs().max().item(),
                    "loss_rank0": losses, "loss_full": ref_losses}, open(args.out, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def nas_phases_mode(args, rank, world):
+    """The three phases of search.py:290-405 on the HIP NAS_MODEL under DistributedDataParallel: width search
+    (length_grad(False)), length search (length_grad(True), mask_grad(True)), kernel training (both off), with the model
+    unwrapped (`.module`) and wrapped again at each change (search.py:329-333,372-376)."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from mobilesuperresolution_amd.models import get_model, wrap_ddp
+    ns = argparse.Namespace(model_type="NAS_MODEL", image_mean=0.5, num_channels=3, scale=2, num_blocks=4, num_residual_units=24,
+                            hot_dtype=args.dtype, width_search=True, length_search=True, pretrained=False)
+    g = torch.Generator().manual_seed(77)
+    n = 2 * world
+    x, hr = torch.rand(n, 3, 24, 36, generator=g), torch.rand(n, 3, 48, 72, generator=g)
+    per = n // world
+    xs, hs = x[rank * per:(rank + 1) * per].cuda(), hr[rank * per:(rank + 1) * per].cuda()
+
+    def iterate(ddp, opt, its=3):
+        for _ in range(its):
+            opt.zero_grad(set_to_none=True)
+            out, speed = ddp(xs)
+            (torch.nn.functional.l1_loss(out, hs) + 1e-3 * speed.sum()).backward()
+            opt.step()
+        torch.cuda.synchronize()
+
+    def snapshot(m):
+        return {k: v.detach().clone() for k, v in m.named_parameters()}
+
+    def changed(m, before):
+        return sorted(k for k, v in m.named_parameters() if not torch.equal(v.detach(), before[k]))
+
+    def replicas_equal(m):
+        mine = torch.cat([p.detach().float().reshape(-1) for p in m.parameters()]).cpu()
+        got = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        return all(torch.equal(got[0], t) for t in got[1:])
+
+    res = {}
+    # the hazard itself: stock wrapping of the reference-shaped model fails on the second iteration
+    torch.manual_seed(0)
+    model = get_model(ns).cuda().train()
+    model.length_grad(False)
+    stock = DDP(model, device_ids=[0], output_device=0)
+    try:
+        iterate(stock, torch.optim.Adam(stock.parameters(), 1e-3), its=2)
+        res["stock_ddp_error"] = None
+    except RuntimeError as e:
+        res["stock_ddp_error"] = str(e)[:160]
+    del stock
+    dist.barrier()
+
+    torch.manual_seed(0)
+    model = get_model(ns).cuda().train()
+    # phase 1: width-only search (search.py:290-327)
+    model.length_grad(False)
+    ddp = wrap_ddp(model, device_ids=[0], output_device=0)
+    before = snapshot(model)
+    iterate(ddp, torch.optim.Adam(ddp.parameters(), 1e-3 * 10 / world))
+    res["phase1_changed"], res["phase1_equal"] = changed(model, before), replicas_equal(model)
+    # phase 2: length search (search.py:329-368)
+    model = ddp.module
+    model.length_grad(True)
+    model.mask_grad(True)
+    res["phase2_frozen_now"] = [k for k, p in model.named_parameters() if not p.requires_grad and "speed_estimator" not in k]
+    ddp = wrap_ddp(model, device_ids=[0], output_device=0)
+    res["phase2_frozen_by_wrap"] = sorted(k for k, p in model.named_parameters()
+                                          if not p.requires_grad and "speed_estimator" not in k)
+    before = snapshot(model)
+    iterate(ddp, torch.optim.Adam(ddp.parameters(), 1e-3))
+    res["phase2_changed"], res["phase2_equal"] = changed(model, before), replicas_equal(model)
+    # phase 3: kernel training (search.py:370-405)
+    model = ddp.module
+    model.length_grad(False)
+    model.mask_grad(False)
+    ddp = wrap_ddp(model, device_ids=[0], output_device=0)
+    before = snapshot(model)
+    iterate(ddp, torch.optim.Adam(ddp.parameters(), 1e-3))
+    res["phase3_changed"], res["phase3_equal"] = changed(model, before), replicas_equal(model)
+    if rank == 0:
+        json.dump(res, open(args.out, "w"))
     dist.barrier()
     dist.destroy_process_group()
 

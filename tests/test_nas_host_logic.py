@@ -46,3 +46,55 @@ def test_batched_gate_matches_condition_function():
         assert float(b1) == float(gates[i, 0]) and float(b2) == float(gates[i, 1]) and float(b1 + b2) == 1.0
         (b1 * up[i, 0] + b2 * up[i, 1]).sum().backward()
         assert torch.equal(x1.grad, a1.grad[i:i + 1]) and torch.equal(x2.grad, a2.grad[i:i + 1])   # straight-through
+
+
+def test_load_pretrained_is_positional_like_the_reference(tmp_path):
+    """reference wdsr_b.py:235-250: walk parameters(), take the checkpoint's next tensor when shapes agree.  A BASIC_MODEL
+    checkpoint therefore fills the head (bias, weight_g, weight_v) and then stalls on body.0's 144-wide bias."""
+    import argparse
+    import numpy as np
+    import torch
+    from mobilesuperresolution_amd.models import get_model
+    torch.manual_seed(3)
+    sd = {"head.0.bias": torch.randn(24), "head.0.weight_g": torch.randn(24, 1, 1, 1), "head.0.weight_v": torch.randn(24, 3, 3, 3),
+          "body.0.body.0.bias": torch.randn(144), "body.0.body.0.weight_g": torch.randn(144, 1, 1, 1)}
+    path = str(tmp_path / "wdsr_b_x2_4_24.pt")
+    torch.save(sd, path)
+    ns = argparse.Namespace(model_type="NAS_MODEL", image_mean=0.5, num_channels=3, scale=2, num_blocks=4, num_residual_units=24,
+                            width_search=True, length_search=False, pretrained=False)
+    torch.manual_seed(0)
+    m = get_model(ns)
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    assert m.load_pretrained(path) == 3
+    for k, v in m.named_parameters():
+        if k in ("head.bias", "head.weight_g", "head.weight_v"):
+            assert torch.equal(v, sd["head.0." + k.split(".")[1]])
+        else:
+            assert torch.equal(v, before[k]), k
+    ns.pretrained, ns.pretrained_path = True, path
+    m2 = get_model(ns)
+    assert torch.equal(m2.head.weight_v, sd["head.0.weight_v"])
+    ns.pretrained_path = str(tmp_path / "missing.pt")
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        get_model(ns)
+    # parameter registration order is the reference's (fixture G10 lists the reference's own named_parameters order)
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "g10_nas_model.npz"))
+    ref_order = [k[2:] for k in z.keys() if k.startswith("p/")]
+    ns16 = argparse.Namespace(**{**vars(ns), "pretrained": False, "num_blocks": len({k.split(".")[1] for k in ref_order if k.startswith("body.")})})
+    mine = [k for k, _ in get_model(ns16).named_parameters() if not k.startswith("speed_estimator")]
+    assert mine == ref_order
+
+
+def test_freeze_gradless_parameters_names():
+    import argparse
+    from mobilesuperresolution_amd.models import get_model
+    ns = argparse.Namespace(model_type="NAS_MODEL", image_mean=0.5, num_channels=3, scale=2, num_blocks=3, num_residual_units=24,
+                            width_search=True, length_search=False, pretrained=False)
+    m = get_model(ns)
+    m.length_grad(True)
+    got = m.freeze_gradless_parameters()
+    assert got == [f"body.{i}.{n}" for i in range(3) for n in ("beta", "beta1", "beta2")]
+    assert m.freeze_gradless_parameters() == []
+    assert all(p.requires_grad for k, p in m.named_parameters() if k.endswith((".alpha1", ".alpha2", ".alpha")))
