@@ -147,18 +147,45 @@ int sr_c3_bwd_data(const void* dA, const void* A, const void* add, void* dx, con
 int sr_c3_wgrad(const void* x, const void* dA, const void* A, float* partial, int wgs, int N, int H, int W,
                 int CI, int act, int dtype, sr_stream_t stream);
 
+/* The first conv's input gathered on the fly: what the reference builds per frame and direction as
+ * `flow_warp(feat_prop, flow.permute(0,2,3,1))` then `torch.cat([x_i, feat_prop], dim=1)` (models/basicvsr_arch.py:74-76,
+ * 85-87; mvvsr_arch.py:79-81,90-92).  frame [N][3][H][W] fp32 (batch stride frame_bs elements); state [N][H][W][24] in the
+ * hot dtype = the previous call's a_nb (NULL: zero state, the first frame of a direction); flow [N][2][H][W] fp32, x then
+ * y displacement, batch stride flow_bs (NULL: no warp).  Backward only: flow_bound = device scalar >= max |flow| (read by
+ * the kernel, no host sync; it sizes the gather window of the atomics-free d state); dstate [N][H][W][24] hot dtype (NULL:
+ * not wanted); dflow [N][2][H][W] fp32 with batch stride dflow_bs (NULL: not wanted). */
+typedef struct sr_c3_warp {
+  const float* frame; long frame_bs;
+  const void* state;
+  const float* flow; long flow_bs;
+  const float* flow_bound;
+  void* dstate;
+  float* dflow; long dflow_bs;
+} sr_c3_warp_t;
+
+/* Slabs -> gradient of the trunk's flat parameter inside sr_c3_trunk_bwd (NULL: the caller reduces `parts` itself):
+ * gflat[off_k + i] = sum_w parts[k][w][sidx[i]], conv 0 through sidx0 (n0 elements), convs 1..2nb through sidx1 (n1
+ * elements each, consecutive in gflat from element n0 on). */
+typedef struct sr_c3_unpack {
+  const int* sidx0; const int* dst0; int n0;
+  const int* sidx1; const int* dst1; int n1;
+  float* gflat;
+} sr_c3_unpack_t;
+
 /* The whole propagation trunk, ConvResidualBlocks.forward (models/basicvsr_arch.py:108-147), from one call.
- * x0 [N,H,W,ci0] (ci0 = 32: the 27-channel concat zero-padded, or 24); acts [(nb+1)][N,H,W,24] receives a_0..a_nb
- * (a_nb = output), mids [nb][N,H,W,24] the post-ReLU conv1 outputs; blob = every conv's packed weights in one
- * buffer, conv k (0 = first conv, 1+2i / 2+2i = conv1 / conv2 of block i) at ELEMENT offset blob_off[k] (host array). */
-int sr_c3_trunk_fwd(const void* x0, void* acts, void* mids, const void* blob, const long* blob_off, int nb,
-                    int N, int H, int W, int ci0, int dtype, sr_stream_t stream);
+ * Input: EITHER x0 [N,H,W,ci0] (ci0 = 32: the 27-channel concat zero-padded, or 24) OR warp (frame, state, flow; ci0 = 32)
+ * -- exactly one of the two is non-NULL.  acts [(nb+1)][N,H,W,24] receives a_0..a_nb (a_nb = output), mids [nb][N,H,W,24]
+ * the post-ReLU conv1 outputs; blob = every conv's packed weights in one buffer, conv k (0 = first conv, 1+2i / 2+2i =
+ * conv1 / conv2 of block i) at ELEMENT offset blob_off[k] (host array). */
+int sr_c3_trunk_fwd(const void* x0, const sr_c3_warp_t* warp, void* acts, void* mids, const void* blob,
+                    const long* blob_off, int nb, int N, int H, int W, int ci0, int dtype, sr_stream_t stream);
 /* Its backward.  ga [(nb+1)][N,H,W,24]: the caller writes d(loss)/d(a_nb) into slot nb, the call fills the other
  * slots; gt [nb][...] scratch (gradients at the post-ReLU points); parts [(1+2nb)][wgs][9*1024] fp32 weight-gradient
- * slabs per conv (layout packing.c3_tables "grad"); dx0 (may be NULL) = gradient w.r.t. x0. */
-int sr_c3_trunk_bwd(const void* x0, const void* acts, const void* mids, void* ga, void* gt, const void* blob,
-                    const long* blob_off, float* parts, void* dx0, int nb, int wgs, int N, int H, int W, int ci0,
-                    int dtype, sr_stream_t stream);
+ * slabs per conv (layout packing.c3_tables "grad"); dx0 (may be NULL unless warp->dstate / dflow is asked for) =
+ * gradient w.r.t. the first conv's 32-channel input. */
+int sr_c3_trunk_bwd(const void* x0, const sr_c3_warp_t* warp, const void* acts, const void* mids, void* ga, void* gt,
+                    const void* blob, const long* blob_off, float* parts, void* dx0, const sr_c3_unpack_t* unpack, int nb,
+                    int wgs, int N, int H, int W, int ci0, int dtype, sr_stream_t stream);
 
 /* flow_warp, models/spynet_arch.py:98-129 (bilinear, zeros padding, align_corners=True): x, out NCHW fp32;
  * flow (N,H,W,2).  Backward: dx (zero-filled by the caller, may be NULL) and dflow (may be NULL). */

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SR_HOTPATH_LIB_PATH (tools/ only): an explicitly named build of the same sources (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("SR_HOTPATH_LIB_PATH") or os.path.join(
     _HERE, "libsr_hotpath_dbg.so" if os.environ.get("SR_HOTPATH_DEBUG_LIB") == "1" else "libsr_hotpath.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
 
 _P, _I, _Z, _L, _F = c_void_p, c_int, c_size_t, ctypes.c_long, ctypes.c_float
@@ -30,8 +30,8 @@ SIGNATURES = {
     "sr_probe_launch_floor": ([_P, _I, _I, _I, _I, _I, _P], _I),
     "sr_probe_launch_floor_graph": ([_P, _I, _I, _I, _I, _I, _I, _P, _P], _I),
     "sr_debug_set_stamps": ([_P], _I),
-    "sr_c3_trunk_fwd": ([_P] * 5 + [_I] * 6 + [_P], _I),
-    "sr_c3_trunk_bwd": ([_P] * 9 + [_I] * 7 + [_P], _I),
+    "sr_c3_trunk_fwd": ([_P] * 6 + [_I] * 6 + [_P], _I),
+    "sr_c3_trunk_bwd": ([_P] * 11 + [_I] * 7 + [_P], _I),
     "sr_tail_bwd": ([_P, _P, _P, _F, _P, _P, _P] + [_I] * 7 + [_P], _I),
     "sr_nas_dw_wgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block_fwd_repeat": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
@@ -83,6 +83,17 @@ class WdsrNet(ctypes.Structure):
          ("x", _P), ("acts", _P), ("grads", _P), ("out", _P), ("dout", _P), ("tsave", _P), ("dtsave", _P),
          ("hr", _P), ("loss_kind", _I), ("loss_gscale", _F), ("loss_part", _P),
          ("nb_split", _I), ("chan_split", _I), ("bias_split", _I)])
+
+
+class C3Warp(ctypes.Structure):
+    """mirror of sr_c3_warp_t"""
+    _fields_ = [("frame", _P), ("frame_bs", _L), ("state", _P), ("flow", _P), ("flow_bs", _L), ("flow_bound", _P),
+                ("dstate", _P), ("dflow", _P), ("dflow_bs", _L)]
+
+
+class C3Unpack(ctypes.Structure):
+    """mirror of sr_c3_unpack_t"""
+    _fields_ = [("sidx0", _P), ("dst0", _P), ("n0", _I), ("sidx1", _P), ("dst1", _P), ("n1", _I), ("gflat", _P)]
 
 
 class AdamScalars(ctypes.Structure):

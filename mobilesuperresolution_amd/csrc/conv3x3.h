@@ -8,6 +8,7 @@
 // 32-wide LDS row) at the centre tap.  Activation: 0 none, 1 ReLU, 2 LeakyReLU(0.1).
 #pragma once
 #include "wdsr_block.h"
+#include "flow_warp.h"
 
 struct C3Cfg {
   static constexpr int CO = 24, COC = 3;                        // output channels / 8-channel chunks
@@ -60,6 +61,92 @@ SR_DEV void c3_stage_x(T* Xs, const T* __restrict__ xin, int H, int W, int ty0, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The first conv's input gathered on the fly (f1): the reference builds it per frame and direction as
+//   feat_prop = flow_warp(feat_prop, flow.permute(0, 2, 3, 1)); feat_prop = torch.cat([x_i, feat_prop], dim=1)
+// (models/basicvsr_arch.py:74-76,85-87 / mvvsr_arch.py:79-81,90-92).  Here the 3 frame channels and the 24 bilinear
+// samples of the recurrent state land straight in the conv's LDS tile [rows][32] = frame 0..2 | state 3..26 | ones 27:
+// no warped tensor, no concat, no NCHW -> NHWC copy.  The blend is flow_warp_fwd_kernel's, term by term.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct C3WarpSrc {
+  const float* frame;      // [N][3][H][W] fp32, batch stride frame_bs elements
+  const T* state;          // [N][H][W][24] (the previous call's output in the hot layout); nullptr = zero state
+  const float* flow;       // [N][2][H][W] fp32: x then y displacement in pixels, batch stride flow_bs; nullptr = no warp
+  long frame_bs, flow_bs;
+};
+
+template <typename T> SR_DEV void c3_warp_chunk(float (&o)[8], const T* __restrict__ st, int W, const WarpTaps& t, int chunk) {
+  typedef typename FragOf<T>::type FragT;
+  const float w00 = (1.f - t.wx) * (1.f - t.wy), w01 = t.wx * (1.f - t.wy), w10 = (1.f - t.wx) * t.wy, w11 = t.wx * t.wy;
+  const T* p00 = st + ((size_t)t.y0 * W + t.x0) * C3Cfg::CO + chunk * 8;
+  FragT a, b, c, d;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a[j] = (T)0.f; b[j] = (T)0.f; c[j] = (T)0.f; d[j] = (T)0.f; }
+  if (t.vy0 && t.vx0) a = *reinterpret_cast<const FragT*>(p00);
+  if (t.vy0 && t.vx1) b = *reinterpret_cast<const FragT*>(p00 + C3Cfg::CO);
+  if (t.vy1 && t.vx0) c = *reinterpret_cast<const FragT*>(p00 + (size_t)W * C3Cfg::CO);
+  if (t.vy1 && t.vx1) d = *reinterpret_cast<const FragT*>(p00 + (size_t)(W + 1) * C3Cfg::CO);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = 0.f;
+    if (t.vy0 && t.vx0) v += w00 * (float)a[j];
+    if (t.vy0 && t.vx1) v += w01 * (float)b[j];
+    if (t.vy1 && t.vx0) v += w10 * (float)c[j];
+    if (t.vy1 && t.vx1) v += w11 * (float)d[j];
+    o[j] = v;
+  }
+}
+
+SR_DEV WarpTaps c3_taps_of(const float* __restrict__ flow, long flow_bs, int n, int Y, int X, int H, int W) {
+  if (!flow) return warp_taps((float)X, (float)Y, H, W);
+  const float* f = flow + (size_t)n * flow_bs + (size_t)Y * W + X;
+  return warp_taps(warp_pos((float)X + f[0], W), warp_pos((float)Y + f[(size_t)H * W], H), H, W);
+}
+
+template <typename T, bool HALO, int NTHREADS>
+SR_DEV void c3_stage_x_warp(T* Xs, const C3WarpSrc<T>& s, int n, int H, int W, int ty0, int tx0, int tid) {
+  typedef typename FragOf<T>::type FragT;
+  constexpr int ROWS = HALO ? C3Cfg::NPXH_PAD + 2 : C3Cfg::NPXC + 1;
+  constexpr int LIVE = HALO ? C3Cfg::NPXH : C3Cfg::NPXC;
+  constexpr int TWW = HALO ? C3Cfg::HW : C3Cfg::TW;
+  constexpr int TOTAL = ROWS * 4;
+  const T* st = s.state ? s.state + (size_t)n * H * W * C3Cfg::CO : nullptr;
+#pragma unroll 2
+  for (int idx = tid; idx < TOTAL; idx += NTHREADS) {
+    const int p = idx >> 2, c = idx & 3;
+    FragT v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (T)0.f;
+    if (p < LIVE) {
+      const int py = p / TWW, px = p - py * TWW;
+      const int Y = ty0 - (HALO ? 1 : 0) + py, X = tx0 - (HALO ? 1 : 0) + px;
+      if (Y >= 0 && Y < H && X >= 0 && X < W) {
+        if (c == 0) {
+          const float* fr = s.frame + (size_t)n * s.frame_bs + (size_t)Y * W + X;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) v[j] = (T)fr[(size_t)j * H * W];
+        }
+        if (st) {                                   // LDS channel 8c + j holds state channel 8c + j - 3
+          const WarpTaps t = c3_taps_of(s.flow, s.flow_bs, n, Y, X, H, W);
+          float lo[8], hi[8];
+          if (c >= 1) {
+            c3_warp_chunk<T>(lo, st, W, t, c - 1);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v[j] = (T)lo[5 + j];
+          }
+          if (c <= 2) {
+            c3_warp_chunk<T>(hi, st, W, t, c);
+#pragma unroll
+            for (int j = 3; j < 8; ++j) v[j] = (T)hi[j - 3];
+          }
+        }
+      }
+    }
+    if (c == 3) v[3] = (T)1.f;                     // the ones channel (27) that carries the bias
+    *reinterpret_cast<FragT*>(Xs + idx * 8) = v;
+  }
+}
+
 // dz tile with halo [NPXH_PAD + 2][24]: dz = dA * act'(A) (zero outside the image)
 template <typename T, int ACT, int NTHREADS>
 SR_DEV void c3_stage_dz(T* DZ, const T* __restrict__ dA, const T* __restrict__ A, int H, int W, int ty0, int tx0, int tid) {
@@ -97,10 +184,11 @@ SR_DEV void c3_stage_dz(T* DZ, const T* __restrict__ dA, const T* __restrict__ A
 // ---------------------------------------------------------------------------------------------
 // forward: y = act(conv3x3(x) + b) [+ res].  grid = (tiles, N); one wave per 32-pixel output tile.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int CI, int ONES, int ACT, bool ADD>
+template <typename T, int CI, int ONES, int ACT, bool ADD, bool WARP = false>
 __global__ __launch_bounds__((64 * C3Cfg::NPT_O)) void c3_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                                      T* __restrict__ y, const T* __restrict__ wblob,
-                                                                     int H, int W, int tiles_x) {
+                                                                     int H, int W, int tiles_x, C3WarpSrc<T> warp) {
+  static_assert(!WARP || (CI == 32 && ONES == 27), "the gathered input is the 27-channel concat");
   typedef C3Cfg C;
   typedef typename FragOf<T>::half_type HalfT;
   constexpr int NTHREADS = 64 * C::NPT_O;
@@ -116,7 +204,8 @@ __global__ __launch_bounds__((64 * C3Cfg::NPT_O)) void c3_fwd_kernel(const T* __
   } else {
     wsrc.p0 = wblob;
   }
-  c3_stage_x<T, CI, ONES, true, NTHREADS>(smem, x + (size_t)n * H * W * CI, H, W, ty0, tx0, tid);
+  if constexpr (WARP) c3_stage_x_warp<T, true, NTHREADS>(smem, warp, n, H, W, ty0, tx0, tid);
+  else c3_stage_x<T, CI, ONES, true, NTHREADS>(smem, x + (size_t)n * H * W * CI, H, W, ty0, tx0, tid);
   __syncthreads();
   wsrc.tile();
   const int ot = wave;
@@ -209,11 +298,11 @@ __global__ __launch_bounds__((64 * C3Cfg::NPT_O)) void c3_bwd_data_kernel(const 
 // weight gradient: slab = 9 tiles [u][ci rows, co cols], dW[co, ci, tap] = tile[8 - tap]; the ones
 // channel row of the centre tile is db.  Wave u owns tile u and walks all pixel tiles of each tile.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int CI, int ONES, int ACT>
+template <typename T, int CI, int ONES, int ACT, bool WARP = false>
 __global__ __launch_bounds__((64 * 9)) void c3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dA,
                                                             const T* __restrict__ A, float* __restrict__ partial, int N,
                                                             int H, int W, int tiles_x, int tiles_per_img, long x_ls,
-                                                            long d_ls, long a_ls, long p_ls) {
+                                                            long d_ls, long a_ls, long p_ls, C3WarpSrc<T> warp) {
   typedef C3Cfg C;
   constexpr int NTHREADS = 576;
   // blockIdx.y = layer: several convolutions of the same kind in one launch (element strides between layers)
@@ -231,7 +320,8 @@ __global__ __launch_bounds__((64 * 9)) void c3_wgrad_kernel(const T* __restrict_
     const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
     const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
     __syncthreads();
-    c3_stage_x<T, CI, ONES, false, NTHREADS>(XC, x + (size_t)n * H * W * CI, H, W, ty0, tx0, tid);
+    if constexpr (WARP) c3_stage_x_warp<T, false, NTHREADS>(XC, warp, n, H, W, ty0, tx0, tid);
+    else c3_stage_x<T, CI, ONES, false, NTHREADS>(XC, x + (size_t)n * H * W * CI, H, W, ty0, tx0, tid);
     c3_stage_dz<T, ACT, NTHREADS>(DZ, dA + (size_t)n * H * W * C::CO, A + (size_t)n * H * W * C::CO, H, W, ty0, tx0, tid);
     __syncthreads();
     constexpr int UNR = sizeof(T) == 2 ? 3 : 1;
@@ -482,5 +572,75 @@ __global__ __launch_bounds__((64 * C3Pair::NPT_H)) void c3_resblock_bwd_data_ker
         *reinterpret_cast<HalfT*>(ga + o + gi * 8 + hh * 4) = v;
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// flow_warp backward for the gathered first conv, WITHOUT float atomics.  g = dx0 (the first conv's input gradient,
+// [N][H][W][32]: channels 3..26 are the gradient of the warped state).
+//   d state[s] = sum over output pixels o that sampled s of w_tap(o) * g[o]      (gather form: each source pixel walks
+//                the window |o - s| <= RW, RW = ceil(max |flow|) + 1 read from a device scalar the caller computed
+//                once per clip; the summation order is fixed, so the result is deterministic)
+//   d flow[o]  = sum_c g[o][c] * d(bilinear)/d(position)                         (per output pixel, optional)
+// One thread per (pixel, 8-channel chunk of the state).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void c3_warp_bwd_kernel(const T* __restrict__ g, C3WarpSrc<T> s, const float* __restrict__ flow_bound,
+                                                          T* __restrict__ dstate, float* __restrict__ dflow, long dflow_bs,
+                                                          int H, int W) {
+  typedef typename FragOf<T>::type FragT;
+  const int n = blockIdx.y;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int p = idx / 3, chunk = idx - p * 3;
+  if (p >= H * W) return;
+  const int sy = p / W, sx = p - sy * W;
+  int rw = 1;
+  if (s.flow) {
+    const float b = *flow_bound;
+    rw = (b < 0.f ? 0 : (b > 1e6f ? 1000000 : (int)ceilf(b))) + 1;
+  } else {
+    rw = 0;
+  }
+  const T* gi = g + (size_t)n * H * W * 32;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const int y_lo = sy - rw < 0 ? 0 : sy - rw, y_hi = sy + rw >= H ? H - 1 : sy + rw;
+  const int x_lo = sx - rw < 0 ? 0 : sx - rw, x_hi = sx + rw >= W ? W - 1 : sx + rw;
+  for (int oy = y_lo; oy <= y_hi; ++oy)
+    for (int ox = x_lo; ox <= x_hi; ++ox) {
+      const WarpTaps t = c3_taps_of(s.flow, s.flow_bs, n, oy, ox, H, W);
+      const int dy = sy - t.y0, dx = sx - t.x0;
+      if (dy < 0 || dy > 1 || dx < 0 || dx > 1) continue;
+      const float wgt = (dx ? t.wx : 1.f - t.wx) * (dy ? t.wy : 1.f - t.wy);
+      // state channels 8 chunk .. +7 sit at g channels 3 + 8 chunk ..: two aligned chunks, shifted by 3
+      const T* row = gi + ((size_t)oy * W + ox) * 32 + chunk * 8;
+      const FragT a = *reinterpret_cast<const FragT*>(row), b = *reinterpret_cast<const FragT*>(row + 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += wgt * (float)(j < 5 ? a[3 + j] : b[j - 5]);
+    }
+  FragT o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (T)acc[j];
+  *reinterpret_cast<FragT*>(dstate + ((size_t)n * H * W + p) * C3Cfg::CO + chunk * 8) = o;
+
+  if (dflow && chunk == 0) {                         // this thread's pixel as an OUTPUT pixel
+    float gx = 0.f, gy = 0.f;
+    if (s.state && s.flow) {
+      const WarpTaps t = c3_taps_of(s.flow, s.flow_bs, n, sy, sx, H, W);
+      const T* st = s.state + (size_t)n * H * W * C3Cfg::CO + ((size_t)t.y0 * W + t.x0) * C3Cfg::CO;
+      const T* grow = gi + (size_t)p * 32;
+      for (int c = 0; c < C3Cfg::CO; ++c) {
+        const float gg = (float)grow[3 + c];
+        const float v00 = (t.vy0 && t.vx0) ? (float)st[c] : 0.f, v01 = (t.vy0 && t.vx1) ? (float)st[C3Cfg::CO + c] : 0.f;
+        const float v10 = (t.vy1 && t.vx0) ? (float)st[(size_t)W * C3Cfg::CO + c] : 0.f;
+        const float v11 = (t.vy1 && t.vx1) ? (float)st[(size_t)(W + 1) * C3Cfg::CO + c] : 0.f;
+        gx += gg * ((v01 - v00) * (1.f - t.wy) + (v11 - v10) * t.wy);
+        gy += gg * ((v10 - v00) * (1.f - t.wx) + (v11 - v01) * t.wx);
+      }
+    }
+    float* df = dflow + (size_t)n * dflow_bs + p;
+    df[0] = W > 1 ? gx : 0.f;
+    df[(size_t)H * W] = H > 1 ? gy : 0.f;
   }
 }

@@ -12,7 +12,7 @@
 #include "train_step.h"
 #include "pixel_shuffle.h"
 
-extern "C" int sr_abi_version(void) { return 4; }
+extern "C" int sr_abi_version(void) { return 5; }
 
 namespace {
 
@@ -369,12 +369,23 @@ inline C3Grid c3_grid(int N, int H, int W) {
   g.grid = dim3(g.tpi, N);
   return g;
 }
+template <typename T> C3WarpSrc<T> c3_warp_src(const sr_c3_warp_t* w) {
+  C3WarpSrc<T> s{};
+  if (w) { s.frame = w->frame; s.state = (const T*)w->state; s.flow = w->flow; s.frame_bs = w->frame_bs; s.flow_bs = w->flow_bs; }
+  return s;
+}
 template <typename T>
-int c3_fwd_t(const void* x, const void* res, void* y, const void* w, int N, int H, int W, int CI, int act, hipStream_t st) {
+int c3_fwd_t(const void* x, const void* res, void* y, const void* w, int N, int H, int W, int CI, int act, hipStream_t st,
+             const sr_c3_warp_t* warp = nullptr) {
   const C3Grid g = c3_grid(N, H, W);
   const dim3 blk(64 * C3Cfg::NPT_O);
-#define L(CI_, ONES_, ACT_, ADD_) hipLaunchKernelGGL((c3_fwd_kernel<T, CI_, ONES_, ACT_, ADD_>), g.grid, blk, 0, st, (const T*)x, (const T*)res, (T*)y, (const T*)w, H, W, g.tx)
-  if (CI == 32 && act == 2 && !res) L(32, 27, 2, false);
+  const C3WarpSrc<T> ws = c3_warp_src<T>(warp);
+#define L(CI_, ONES_, ACT_, ADD_) hipLaunchKernelGGL((c3_fwd_kernel<T, CI_, ONES_, ACT_, ADD_>), g.grid, blk, 0, st, (const T*)x, (const T*)res, (T*)y, (const T*)w, H, W, g.tx, ws)
+  if (warp) {
+    if (CI != 32 || act != 2 || res) return -1;
+    hipLaunchKernelGGL((c3_fwd_kernel<T, 32, 27, 2, false, true>), g.grid, blk, 0, st, (const T*)nullptr, (const T*)nullptr, (T*)y,
+                       (const T*)w, H, W, g.tx, ws);
+  } else if (CI == 32 && act == 2 && !res) L(32, 27, 2, false);
   else if (CI == 24 && act == 1 && !res) L(24, 24, 1, false);
   else if (CI == 24 && act == 0 && res) L(24, 24, 0, true);
   else if (CI == 24 && act == 0 && !res) L(24, 24, 0, false);
@@ -400,10 +411,16 @@ int c3_bwd_t(const void* dA, const void* A, const void* add, void* dx, const voi
 }
 template <typename T>
 int c3_wgrad_t(const void* x, const void* dA, const void* A, float* partial, int wgs, int N, int H, int W, int CI, int act,
-               hipStream_t st, int layers = 1, long x_ls = 0, long d_ls = 0, long a_ls = 0, long p_ls = 0) {
+               hipStream_t st, int layers = 1, long x_ls = 0, long d_ls = 0, long a_ls = 0, long p_ls = 0,
+               const sr_c3_warp_t* warp = nullptr) {
   const C3Grid g = c3_grid(N, H, W);
-#define L(CI_, ONES_, ACT_) hipLaunchKernelGGL((c3_wgrad_kernel<T, CI_, ONES_, ACT_>), dim3(wgs, layers), dim3(576), 0, st, (const T*)x, (const T*)dA, (const T*)A, partial, N, H, W, g.tx, g.tpi, x_ls, d_ls, a_ls, p_ls)
-  if (CI == 32 && act == 2) L(32, 27, 2);
+  const C3WarpSrc<T> ws = c3_warp_src<T>(warp);
+#define L(CI_, ONES_, ACT_) hipLaunchKernelGGL((c3_wgrad_kernel<T, CI_, ONES_, ACT_>), dim3(wgs, layers), dim3(576), 0, st, (const T*)x, (const T*)dA, (const T*)A, partial, N, H, W, g.tx, g.tpi, x_ls, d_ls, a_ls, p_ls, ws)
+  if (warp) {
+    if (CI != 32 || act != 2 || layers != 1) return -1;
+    hipLaunchKernelGGL((c3_wgrad_kernel<T, 32, 27, 2, true>), dim3(wgs, 1), dim3(576), 0, st, (const T*)nullptr, (const T*)dA,
+                       (const T*)A, partial, N, H, W, g.tx, g.tpi, x_ls, d_ls, a_ls, p_ls, ws);
+  } else if (CI == 32 && act == 2) L(32, 27, 2);
   else if (CI == 24 && act == 1) L(24, 24, 1);
   else if (CI == 24 && act == 0) L(24, 24, 0);
   else return -1;
@@ -436,12 +453,12 @@ extern "C" int sr_c3_wgrad(const void* x, const void* dA, const void* A, float* 
 
 // whole propagation trunk (ConvResidualBlocks.forward, models/basicvsr_arch.py:108-147) from one call
 template <typename T>
-static int c3_trunk_fwd_t(const void* x0, void* acts_, void* mids_, const void* blob_, const long* boff, int nb, int N,
-                          int H, int W, int ci0, hipStream_t st) {
+static int c3_trunk_fwd_t(const void* x0, const sr_c3_warp_t* warp, void* acts_, void* mids_, const void* blob_,
+                          const long* boff, int nb, int N, int H, int W, int ci0, hipStream_t st) {
   const size_t act = (size_t)N * H * W * 24;
   T* acts = (T*)acts_; T* mids = (T*)mids_; const T* blob = (const T*)blob_;
   int rc;
-  if ((rc = c3_fwd_t<T>(x0, nullptr, acts, blob + boff[0], N, H, W, ci0, 2, st))) return rc;
+  if ((rc = c3_fwd_t<T>(x0, nullptr, acts, blob + boff[0], N, H, W, ci0, 2, st, warp))) return rc;
   for (int i = 0; i < nb; ++i) {
     if constexpr (sizeof(T) == 2) {                    // one launch per residual block
       const C3Grid g = c3_grid(N, H, W);
@@ -457,9 +474,9 @@ static int c3_trunk_fwd_t(const void* x0, void* acts_, void* mids_, const void* 
   return 0;
 }
 template <typename T>
-static int c3_trunk_bwd_t(const void* x0, const void* acts_, const void* mids_, void* ga_, void* gt_, const void* blob_,
-                          const long* boff, float* parts, void* dx0, int nb, int wgs, int N, int H, int W, int ci0,
-                          hipStream_t st) {
+static int c3_trunk_bwd_t(const void* x0, const sr_c3_warp_t* warp, const void* acts_, const void* mids_, void* ga_, void* gt_,
+                          const void* blob_, const long* boff, float* parts, void* dx0, const sr_c3_unpack_t* up, int nb,
+                          int wgs, int N, int H, int W, int ci0, hipStream_t st) {
   const size_t act = (size_t)N * H * W * 24;
   const T* acts = (const T*)acts_; const T* mids = (const T*)mids_; const T* blob = (const T*)blob_;
   T* ga = (T*)ga_; T* gt = (T*)gt_;
@@ -485,25 +502,50 @@ static int c3_trunk_bwd_t(const void* x0, const void* acts_, const void* mids_, 
     if ((rc = c3_wgrad_t<T>(acts, gt, mids, parts + slot, wgs, N, H, W, 24, 1, st, nb, (long)act, (long)act, (long)act, 2 * slot)))
       return rc;
   }
-  if ((rc = c3_wgrad_t<T>(x0, ga, acts, parts, wgs, N, H, W, ci0, 2, st))) return rc;
+  if ((rc = c3_wgrad_t<T>(x0, ga, acts, parts, wgs, N, H, W, ci0, 2, st, 1, 0, 0, 0, 0, warp))) return rc;
   if (dx0 && (rc = c3_bwd_t<T>(ga, acts, nullptr, dx0, blob + boff[0], N, H, W, ci0, 2, st))) return rc;
+  if (warp && (warp->dstate || warp->dflow)) {       // flow_warp backward, gather form (no float atomics)
+    if (!dx0 || !warp->dstate || (warp->flow && !warp->flow_bound)) return -2;
+    const int threads = H * W * 3;
+    hipLaunchKernelGGL((c3_warp_bwd_kernel<T>), dim3((threads + 255) / 256, N), dim3(256), 0, st, (const T*)dx0, c3_warp_src<T>(warp),
+                       warp->flow_bound, (T*)warp->dstate, warp->dflow, warp->dflow_bs, H, W);
+    SR_HIP_CHECK_LAUNCH();
+  }
+  if (up) {                                          // slabs -> gradient of the flat parameter
+    UnpackSegs us;
+    const long slab = 9 * 1024;
+    us.nseg = 0;
+    int blk = (up->n0 + 63) / 64;
+    us.s[us.nseg++] = UnpackSeg{parts, up->sidx0, up->dst0, 0, 0, slab, wgs, up->n0, 1, 0};
+    if (nb > 0) {
+      us.s[us.nseg++] = UnpackSeg{parts + (size_t)wgs * slab, up->sidx1, up->dst1, (long)up->n0, (long)up->n1, slab, wgs, up->n1, 2 * nb, blk};
+      blk += 2 * nb * ((up->n1 + 63) / 64);
+    }
+    hipLaunchKernelGGL(unpack_all_kernel, dim3(blk), dim3(64 * UNPACK_Q), 0, st, up->gflat, us);
+    SR_HIP_CHECK_LAUNCH();
+  }
   return 0;
 }
-extern "C" int sr_c3_trunk_fwd(const void* x0, void* acts, void* mids, const void* blob, const long* blob_off, int nb,
-                               int N, int H, int W, int ci0, int dtype, sr_stream_t stream) {
-  if (!x0 || !acts || (nb > 0 && !mids) || !blob || !blob_off || nb < 0 || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
-  return dtype == SR_DTYPE_BF16 ? c3_trunk_fwd_t<__bf16>(x0, acts, mids, blob, blob_off, nb, N, H, W, ci0, (hipStream_t)stream)
-                                : c3_trunk_fwd_t<float>(x0, acts, mids, blob, blob_off, nb, N, H, W, ci0, (hipStream_t)stream);
+extern "C" int sr_c3_trunk_fwd(const void* x0, const sr_c3_warp_t* warp, void* acts, void* mids, const void* blob,
+                               const long* blob_off, int nb, int N, int H, int W, int ci0, int dtype, sr_stream_t stream) {
+  if ((!x0) == (!warp) || !acts || (nb > 0 && !mids) || !blob || !blob_off || nb < 0 || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
+  if (warp && (!warp->frame || ci0 != 32 || (warp->flow && !warp->state))) return -2;
+  return dtype == SR_DTYPE_BF16 ? c3_trunk_fwd_t<__bf16>(x0, warp, acts, mids, blob, blob_off, nb, N, H, W, ci0, (hipStream_t)stream)
+                                : c3_trunk_fwd_t<float>(x0, warp, acts, mids, blob, blob_off, nb, N, H, W, ci0, (hipStream_t)stream);
 }
-extern "C" int sr_c3_trunk_bwd(const void* x0, const void* acts, const void* mids, void* ga, void* gt, const void* blob,
-                               const long* blob_off, float* parts, void* dx0, int nb, int wgs, int N, int H, int W, int ci0,
-                               int dtype, sr_stream_t stream) {
-  if (!x0 || !acts || !ga || (nb > 0 && (!mids || !gt)) || !blob || !blob_off || !parts || nb < 0 || wgs <= 0 || N <= 0 ||
+extern "C" int sr_c3_trunk_bwd(const void* x0, const sr_c3_warp_t* warp, const void* acts, const void* mids, void* ga, void* gt,
+                               const void* blob, const long* blob_off, float* parts, void* dx0, const sr_c3_unpack_t* unpack,
+                               int nb, int wgs, int N, int H, int W, int ci0, int dtype, sr_stream_t stream) {
+  if ((!x0) == (!warp) || !acts || !ga || (nb > 0 && (!mids || !gt)) || !blob || !blob_off || !parts || nb < 0 || wgs <= 0 || N <= 0 ||
       H <= 0 || W <= 0 || N > 65535)
     return -2;
+  if (warp && (!warp->frame || ci0 != 32 || (warp->flow && !warp->state))) return -2;
+  if (unpack && (!unpack->sidx0 || !unpack->dst0 || !unpack->gflat || unpack->n0 <= 0 ||
+                 (nb > 0 && (!unpack->sidx1 || !unpack->dst1 || unpack->n1 <= 0))))
+    return -2;
   return dtype == SR_DTYPE_BF16
-             ? c3_trunk_bwd_t<__bf16>(x0, acts, mids, ga, gt, blob, blob_off, parts, dx0, nb, wgs, N, H, W, ci0, (hipStream_t)stream)
-             : c3_trunk_bwd_t<float>(x0, acts, mids, ga, gt, blob, blob_off, parts, dx0, nb, wgs, N, H, W, ci0, (hipStream_t)stream);
+             ? c3_trunk_bwd_t<__bf16>(x0, warp, acts, mids, ga, gt, blob, blob_off, parts, dx0, unpack, nb, wgs, N, H, W, ci0, (hipStream_t)stream)
+             : c3_trunk_bwd_t<float>(x0, warp, acts, mids, ga, gt, blob, blob_off, parts, dx0, unpack, nb, wgs, N, H, W, ci0, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -808,7 +850,7 @@ extern "C" int sr_wdsr_net_backward_part(const sr_wdsr_net_t* n, int part, sr_st
     }
     if (part != 2) add(n->part_tail, n->gt_sidx, n->gt_dst, n->src_tail_off, 0, n->slab_tail, n->wgs_tail, n->n_gt, 1);
     if (part != 1) add(n->part_head, n->gh_sidx, n->gh_dst, n->src_head_off, 0, n->slab_head, n->wgs_head, n->n_gh, 1);
-    hipLaunchKernelGGL(unpack_all_kernel, dim3(blk), dim3(256), 0, st, n->dsrc, us);
+    hipLaunchKernelGGL(unpack_all_kernel, dim3(blk), dim3(64 * UNPACK_Q), 0, st, n->dsrc, us);
   }
   // weight-norm backward over the table rows of this part (rows are in state_dict order: head, body.0 .., tail, skip)
   const int c0 = part == 1 ? n->chan_split : 0, c1 = part == 2 ? n->chan_split : n->n_chan;

@@ -124,8 +124,9 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
 struct UnpackSeg { const float* partial; const int* sidx; const int* dst; long dst_off, dst_stride, slab; int wgs, n, reps, block0; };
 struct UnpackSegs { UnpackSeg s[4]; int nseg; };
 
-__global__ __launch_bounds__(256) void unpack_all_kernel(float* __restrict__ dsrc, UnpackSegs segs) {
-  __shared__ float red[4][64];
+constexpr int UNPACK_Q = 16;                             // slab groups per block: 64 elements x 16 partial sums
+__global__ __launch_bounds__(64 * UNPACK_Q) void unpack_all_kernel(float* __restrict__ dsrc, UnpackSegs segs) {
+  __shared__ float red[UNPACK_Q][64];
   int k = 0;
 #pragma unroll
   for (int i = 1; i < 4; ++i) if (i < segs.nseg && (int)blockIdx.x >= segs.s[i].block0) k = i;
@@ -136,11 +137,15 @@ __global__ __launch_bounds__(256) void unpack_all_kernel(float* __restrict__ dsr
   float acc = 0.f;
   if (rep < sg.reps && i < sg.n) {
     const float* p = sg.partial + (size_t)rep * sg.wgs * sg.slab + sg.sidx[i];
-#pragma unroll 16                                    // many slabs (tail / head): keep 16 loads in flight per thread
-    for (int w = q; w < sg.wgs; w += 4) acc += p[(size_t)w * sg.slab];
+#pragma unroll 8                                     // many slabs (tail / head): keep the loads in flight
+    for (int w = q; w < sg.wgs; w += UNPACK_Q) acc += p[(size_t)w * sg.slab];
   }
   red[q][e] = acc;
   __syncthreads();
-  if (q == 0 && rep < sg.reps && i < sg.n)
-    dsrc[sg.dst_off + (size_t)rep * sg.dst_stride + sg.dst[i]] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+  if (q == 0 && rep < sg.reps && i < sg.n) {
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < UNPACK_Q; ++j) v += red[j][e];
+    dsrc[sg.dst_off + (size_t)rep * sg.dst_stride + sg.dst[i]] = v;
+  }
 }

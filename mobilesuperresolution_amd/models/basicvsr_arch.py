@@ -76,6 +76,17 @@ def _trunk_tables(cin: int, nb: int, device_index: int):
             (ctypes.c_long * len(boff))(*boff), torch.tensor([0.0, 1.0], device=dev))
 
 
+@lru_cache(maxsize=None)
+def _unpack_tables(cin: int, device_index: int):
+    """int32 tables for the slab -> flat-gradient reduction inside sr_c3_trunk_bwd: (sidx0, dst0, sidx1, dst1)"""
+    dev = torch.device("cuda", device_index)
+
+    def mk(t):
+        g = t["grad"].astype(np.int32)
+        return torch.from_numpy(g).to(dev), torch.arange(len(g), dtype=torch.int32, device=dev)
+    return mk(P.c3_tables(cin)) + mk(P.c3_tables(24))
+
+
 class ResidualBlockNoBN(nn.Module):
     """parameter holder: conv1, conv2 (reference models/basicvsr_arch.py:126-147)"""
 
@@ -187,12 +198,37 @@ class ConvResidualBlocks(nn.Module):
             self._blob_key = key
         return self._blob
 
-    def forward(self, fea: torch.Tensor) -> torch.Tensor:
+    def forward(self, fea: torch.Tensor, state=None, flow=None, flow_bound=None, warped: bool = False):
+        if warped:                                   # (frame, state, flow) -> (features, state): see forward_warped
+            return self._forward_warped(fea, state, flow, flow_bound)
         if not fea.is_cuda:
             raise L.HotpathError("ConvResidualBlocks (MI355X hot path) needs CUDA/HIP tensors; there is no CPU fallback")
         if fea.dim() != 4 or fea.shape[1] != self.num_in_ch:
             raise ValueError(f"expected N x {self.num_in_ch} x H x W input, got {tuple(fea.shape)}")
         return _TrunkFunction.apply(fea, self, self.flat)
+
+    def forward_warped(self, frame, state=None, flow=None, flow_bound=None):
+        """through __call__, so that module hooks see the fused step too (their output is the (features, state) pair)"""
+        return self(frame, state, flow, flow_bound, warped=True)
+
+    def _forward_warped(self, frame, state=None, flow=None, flow_bound=None):
+        """The recurrent step of the reference's propagation loops in one call (models/basicvsr_arch.py:74-76,85-87):
+            feat = flow_warp(feat, flow.permute(0, 2, 3, 1)); feat = trunk(torch.cat([frame, feat], dim=1))
+        with the warp and the concat gathered straight into the first conv's LDS tile (csrc/conv3x3.h, c3_stage_x_warp).
+        frame (N,3,H,W) fp32; state = the handle the previous call returned (None: zero state, the first frame of a
+        direction); flow (N,2,H,W) fp32 pixel displacements (None: no warp); flow_bound: 0-dim device tensor >= max|flow|
+        (computed here when omitted).  Returns (features (N,F,H,W) fp32 like the reference's, state handle)."""
+        if self.cin_k != 27:
+            raise NotImplementedError("forward_warped needs a trunk built as ConvResidualBlocks(F + 3, F, n)")
+        if not frame.is_cuda:
+            raise L.HotpathError("ConvResidualBlocks (MI355X hot path) needs CUDA/HIP tensors; there is no CPU fallback")
+        if frame.dim() != 4 or frame.shape[1] != 3:
+            raise ValueError(f"expected N x 3 x H x W frames, got {tuple(frame.shape)}")
+        if flow is not None and state is None:
+            raise ValueError("a flow without a state to warp")
+        if flow is not None and flow_bound is None:
+            flow_bound = flow.detach().abs().amax()
+        return _TrunkWarpFunction.apply(frame, state, flow, flow_bound, self, self.flat)
 
 
 def _launch(name, *args):
@@ -217,7 +253,7 @@ class _TrunkFunction(torch.autograd.Function):
         tabs = _trunk_tables(mod.cin_k, nb, dev.index if dev.index is not None else torch.cuda.current_device())
         acts = torch.empty((nb + 1, n, h, w, 24), dtype=dt, device=dev)              # a_0 .. a_nb
         mids = torch.empty((max(nb, 1), n, h, w, 24), dtype=dt, device=dev)          # t_i = relu(conv1(a_i))
-        _launch("sr_c3_trunk_fwd", x0.data_ptr(), acts.data_ptr(), mids.data_ptr(), blob.data_ptr(), tabs[2], nb, n, h, w,
+        _launch("sr_c3_trunk_fwd", x0.data_ptr(), None, acts.data_ptr(), mids.data_ptr(), blob.data_ptr(), tabs[2], nb, n, h, w,
                 ci0, L.DTYPE_CODE[dt])
         ctx.mod, ctx.x0, ctx.acts, ctx.mids, ctx.blob = mod, x0, acts, mids, blob
         ctx.need_dx = fea.requires_grad
@@ -240,19 +276,121 @@ class _TrunkFunction(torch.autograd.Function):
             ga[nb][..., :mod.num_feat] = dy.permute(0, 2, 3, 1)
         else:
             ga[nb] = dy.permute(0, 2, 3, 1)
+        import ctypes
         parts = torch.empty((1 + 2 * nb, wgs, 9 * 1024), dtype=torch.float32, device=dev)
         dx0 = torch.empty_like(x0) if ctx.need_dx else None
-        _launch("sr_c3_trunk_bwd", x0.data_ptr(), acts.data_ptr(), mids.data_ptr(), ga.data_ptr(), gt.data_ptr(),
-                blob.data_ptr(), boff, parts.data_ptr(), dx0.data_ptr() if dx0 is not None else None, nb, wgs, n, h, w, ci0,
-                L.DTYPE_CODE[dt])
+        s0, d0, s1, d1 = _unpack_tables(mod.cin_k, dev.index if dev.index is not None else torch.cuda.current_device())
+        gflat = torch.empty(s0.numel() + 2 * nb * s1.numel(), dtype=torch.float32, device=dev)      # dW | db of every conv, flat order
+        unpack = L.C3Unpack(s0.data_ptr(), d0.data_ptr(), s0.numel(), s1.data_ptr(), d1.data_ptr(), s1.numel(), gflat.data_ptr())
+        _launch("sr_c3_trunk_bwd", x0.data_ptr(), None, acts.data_ptr(), mids.data_ptr(), ga.data_ptr(), gt.data_ptr(),
+                blob.data_ptr(), boff, parts.data_ptr(), dx0.data_ptr() if dx0 is not None else None, ctypes.byref(unpack), nb, wgs,
+                n, h, w, ci0, L.DTYPE_CODE[dt])
         dfea = None
         if dx0 is not None:
             dfea = torch.empty((n, cin, h, w), dtype=torch.float32, device=dev)
             dfea.copy_(dx0[..., :cin].permute(0, 3, 1, 2))
-        gflat = parts.sum(1).reshape(-1).index_select(0, grad_idx)                   # dW | db of every conv, flat order
         if mod._pad:
             gflat = gflat.index_select(0, mod._unpad_idx)
         return dfea, None, gflat
+
+
+def _inner_contiguous(t):
+    """(N, C, H, W) view whose (C, H, W) block is dense: the kernels take the batch stride as an argument"""
+    _, c, h, w = t.shape
+    return t if t.stride()[1:] == (h * w, w, 1) else t.contiguous()
+
+
+class _TrunkWarpFunction(torch.autograd.Function):
+    """flow_warp -> concat -> whole trunk, forward / backward as one C call each (sr_c3_trunk_fwd / _bwd with a
+    sr_c3_warp_t): outputs (features NCHW fp32, the same features NHWC in the hot dtype = the next call's state)"""
+
+    @staticmethod
+    def forward(ctx, frame, state, flow, bound, mod, flat):
+        import ctypes
+        dt, nb = mod.hot_dtype, mod.num_block
+        n, _, h, w = frame.shape
+        dev = frame.device
+        frame_ = _inner_contiguous(frame.detach().float())
+        flow_ = _inner_contiguous(flow.detach().float()) if flow is not None else None
+        state_ = state.detach() if state is not None else None
+        if state_ is not None and (state_.shape != (n, h, w, 24) or state_.dtype != dt or not state_.is_contiguous()):
+            raise ValueError("state must be the handle returned by the previous forward_warped call of this clip")
+        if flow_ is not None and flow_.shape != (n, 2, h, w):
+            raise ValueError(f"expected N x 2 x H x W flow, got {tuple(flow_.shape)}")
+        bound_ = bound.detach().float().reshape(()) if bound is not None else None
+        with torch.cuda.device(dev):
+            blob = mod._packed(flat)
+            tabs = _trunk_tables(27, nb, dev.index)
+            acts = torch.empty((nb + 1, n, h, w, 24), dtype=dt, device=dev)
+            mids = torch.empty((max(nb, 1), n, h, w, 24), dtype=dt, device=dev)
+            warp = L.C3Warp(frame_.data_ptr(), frame_.stride(0), state_.data_ptr() if state_ is not None else None,
+                            flow_.data_ptr() if flow_ is not None else None, flow_.stride(0) if flow_ is not None else 0,
+                            None, None, None, 0)
+            _launch("sr_c3_trunk_fwd", None, ctypes.byref(warp), acts.data_ptr(), mids.data_ptr(), blob.data_ptr(), tabs[2], nb,
+                    n, h, w, 32, L.DTYPE_CODE[dt])
+            out = torch.empty((n, mod.num_feat, h, w), dtype=torch.float32, device=dev)
+            out.copy_(acts[nb][..., :mod.num_feat].permute(0, 3, 1, 2))
+        ctx.mod, ctx.acts, ctx.mids, ctx.blob = mod, acts, mids, blob
+        ctx.frame, ctx.state, ctx.flow, ctx.bound = frame_, state_, flow_, bound_
+        ctx.need = (frame.requires_grad, state is not None and state.requires_grad, flow is not None and flow.requires_grad)
+        ctx.set_materialize_grads(False)
+        return out, acts[nb]
+
+    @staticmethod
+    def backward(ctx, dy, dnext):
+        import ctypes
+        mod, acts, mids, blob = ctx.mod, ctx.acts, ctx.mids, ctx.blob
+        frame, state, flow, bound = ctx.frame, ctx.state, ctx.flow, ctx.bound
+        dt, nb, nf = mod.hot_dtype, mod.num_block, mod.num_feat
+        _, n, h, w, _ = acts.shape
+        dev = acts.device
+        need_frame, need_state, need_flow = ctx.need
+        wgs = 64
+        with torch.cuda.device(dev):
+            _, _, boff, _ = _trunk_tables(27, nb, dev.index)
+            s0, d0, s1, d1 = _unpack_tables(27, dev.index)
+            ga = torch.empty_like(acts)
+            gt = torch.empty_like(mids)
+            tgt = ga[nb]
+            if dy is not None:
+                src = dy.permute(0, 2, 3, 1)
+                if nf < 24:
+                    tgt.zero_()
+                    tgt[..., :nf] = src
+                    if dnext is not None:
+                        tgt.add_(dnext)
+                elif dnext is not None:
+                    torch.add(src, dnext, out=tgt)
+                else:
+                    tgt.copy_(src)
+            elif dnext is not None:
+                tgt.copy_(dnext)
+            else:
+                tgt.zero_()
+            parts = torch.empty((1 + 2 * nb, wgs, 9 * 1024), dtype=torch.float32, device=dev)
+            need_dx0 = need_frame or need_state or need_flow
+            dx0 = torch.empty((n, h, w, 32), dtype=dt, device=dev) if need_dx0 else None
+            dstate = torch.empty((n, h, w, 24), dtype=dt, device=dev) if (need_state or need_flow) and state is not None else None
+            dflow = torch.empty((n, 2, h, w), dtype=torch.float32, device=dev) if need_flow else None
+            warp = L.C3Warp(frame.data_ptr(), frame.stride(0), state.data_ptr() if state is not None else None,
+                            flow.data_ptr() if flow is not None else None, flow.stride(0) if flow is not None else 0,
+                            bound.data_ptr() if bound is not None else None,
+                            dstate.data_ptr() if dstate is not None else None,
+                            dflow.data_ptr() if dflow is not None else None, 2 * h * w)
+            total = s0.numel() + 2 * nb * s1.numel()
+            gflat = torch.empty(total, dtype=torch.float32, device=dev)
+            unpack = L.C3Unpack(s0.data_ptr(), d0.data_ptr(), s0.numel(), s1.data_ptr(), d1.data_ptr(), s1.numel(), gflat.data_ptr())
+            _launch("sr_c3_trunk_bwd", None, ctypes.byref(warp), acts.data_ptr(), mids.data_ptr(), ga.data_ptr(), gt.data_ptr(),
+                    blob.data_ptr(), boff, parts.data_ptr(), dx0.data_ptr() if dx0 is not None else None, ctypes.byref(unpack),
+                    nb, wgs, n, h, w, 32, L.DTYPE_CODE[dt])
+            dframe = dx0[..., :3].permute(0, 3, 1, 2).float() if need_frame else None
+            if mod._pad:
+                gflat = gflat.index_select(0, mod._unpad_idx)
+        return dframe, (dstate if need_state else None), dflow, None, None, gflat
+
+
+def _fusable(trunk):
+    return isinstance(trunk, ConvResidualBlocks) and trunk.cin_k == 27
 
 
 def propagate(x, flows_forward, flows_backward, backward_trunk, forward_trunk, flow_warp, num_feat=24):
@@ -260,6 +398,21 @@ def propagate(x, flows_forward, flows_backward, backward_trunk, forward_trunk, f
     returns (backward features, forward features) per frame.  x: (b, n, 3, h, w); flows: (b, n-1, 2, h, w)."""
     b, n, _, h, w = x.shape
     out_b, out_f = [], []
+    from .spynet_arch import flow_warp as hot_flow_warp
+    if _fusable(backward_trunk) and _fusable(forward_trunk) and flow_warp is hot_flow_warp and x.is_cuda:
+        # warp + concat gathered into the first conv (ConvResidualBlocks.forward_warped); one bound for the whole clip
+        bound = None
+        if n > 1:
+            bound = torch.maximum(flows_forward.detach().abs().amax(), flows_backward.detach().abs().amax())
+        state = None
+        for i in range(n - 1, -1, -1):
+            feat, state = backward_trunk.forward_warped(x[:, i], state, flows_backward[:, i] if i < n - 1 else None, bound)
+            out_b.insert(0, feat)
+        state = None
+        for i in range(n):
+            feat, state = forward_trunk.forward_warped(x[:, i], state, flows_forward[:, i - 1] if i > 0 else None, bound)
+            out_f.append(feat)
+        return out_b, out_f
     feat = x.new_zeros(b, num_feat, h, w)
     for i in range(n - 1, -1, -1):
         if i < n - 1:

@@ -98,7 +98,7 @@ def test_g11_motion_vector_vsr_module_matches_reference(golden_dir):
     x = d["x"].cuda().requires_grad_(True)
     b, n, _, h, w = x.shape
     feats = {"backward_trunk": [], "forward_trunk": []}
-    hooks = [getattr(m, k).register_forward_hook(lambda mod, i, o, k=k: feats[k].append(o.detach())) for k in feats]
+    hooks = [getattr(m, k).register_forward_hook(lambda mod, i, o, k=k: feats[k].append((o[0] if isinstance(o, tuple) else o).detach())) for k in feats]
     out = m(x, 4 * h, 4 * w)
     for hk in hooks:
         hk.remove()
