@@ -161,6 +161,8 @@ typedef struct sr_c3_warp {
   const float* flow_bound;
   void* dstate;
   float* dflow; long dflow_bs;
+  void* x0_save;   /* optional [N][H][W][32] hot dtype: forward writes the gathered input there, backward reads it for the
+                      first conv's weight gradient instead of gathering again */
 } sr_c3_warp_t;
 
 /* Slabs -> gradient of the trunk's flat parameter inside sr_c3_trunk_bwd (NULL: the caller reduces `parts` itself):

@@ -88,7 +88,7 @@ class WdsrNet(ctypes.Structure):
 class C3Warp(ctypes.Structure):
     """mirror of sr_c3_warp_t"""
     _fields_ = [("frame", _P), ("frame_bs", _L), ("state", _P), ("flow", _P), ("flow_bs", _L), ("flow_bound", _P),
-                ("dstate", _P), ("dflow", _P), ("dflow_bs", _L)]
+                ("dstate", _P), ("dflow", _P), ("dflow_bs", _L), ("x0_save", _P)]
 
 
 class C3Unpack(ctypes.Structure):

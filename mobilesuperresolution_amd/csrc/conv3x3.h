@@ -73,6 +73,7 @@ template <typename T> struct C3WarpSrc {
   const T* state;          // [N][H][W][24] (the previous call's output in the hot layout); nullptr = zero state
   const float* flow;       // [N][2][H][W] fp32: x then y displacement in pixels, batch stride flow_bs; nullptr = no warp
   long frame_bs, flow_bs;
+  T* x0_save;              // forward: the gathered 32-channel input [N][H][W][32], kept for the weight gradient; or nullptr
 };
 
 template <typename T> SR_DEV void c3_warp_chunk(float (&o)[8], const T* __restrict__ st, int W, const WarpTaps& t, int chunk) {
@@ -207,6 +208,20 @@ __global__ __launch_bounds__((64 * C3Cfg::NPT_O)) void c3_fwd_kernel(const T* __
   if constexpr (WARP) c3_stage_x_warp<T, true, NTHREADS>(smem, warp, n, H, W, ty0, tx0, tid);
   else c3_stage_x<T, CI, ONES, true, NTHREADS>(smem, x + (size_t)n * H * W * CI, H, W, ty0, tx0, tid);
   __syncthreads();
+  if constexpr (WARP) {
+    if (warp.x0_save) {                              // the core of the gathered tile, as the unfused path would have built it
+      typedef typename FragOf<T>::type FragT;
+      for (int idx = tid; idx < C::NPXC * 4; idx += NTHREADS) {
+        const int p = idx >> 2, c = idx & 3, py = p / C::TW, px = p - py * C::TW;
+        const int Y = ty0 + py, X = tx0 + px;
+        if (Y < H && X < W) {
+          FragT v = *reinterpret_cast<const FragT*>(smem + ((py + 1) * C::HW + px + 1) * 32 + c * 8);
+          if (c == 3) v[3] = (T)0.f;                 // the ones channel is the staging's, not the tensor's
+          *reinterpret_cast<FragT*>(warp.x0_save + (((size_t)n * H + Y) * W + X) * 32 + c * 8) = v;
+        }
+      }
+    }
+  }
   wsrc.tile();
   const int ot = wave;
   const int oy = (ot / (C::TW / 8)) * 4 + (r >> 3), ox = (ot % (C::TW / 8)) * 8 + (r & 7);
@@ -582,49 +597,88 @@ __global__ __launch_bounds__((64 * C3Pair::NPT_H)) void c3_resblock_bwd_data_ker
 //                the window |o - s| <= RW, RW = ceil(max |flow|) + 1 read from a device scalar the caller computed
 //                once per clip; the summation order is fixed, so the result is deterministic)
 //   d flow[o]  = sum_c g[o][c] * d(bilinear)/d(position)                         (per output pixel, optional)
-// One thread per (pixel, 8-channel chunk of the state).
+// One thread per source pixel, 16 x 16 of them per workgroup.
 // ---------------------------------------------------------------------------------------------
+struct C3WarpBwd {
+  static constexpr int TS = 16;                      // 16 x 16 source pixels per workgroup
+  static constexpr int RW_LDS = 7;                   // windows up to this radius keep the candidates' taps in LDS
+  static constexpr int CW = TS + 2 * RW_LDS, NCAND = CW * CW;
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void c3_warp_bwd_kernel(const T* __restrict__ g, C3WarpSrc<T> s, const float* __restrict__ flow_bound,
                                                           T* __restrict__ dstate, float* __restrict__ dflow, long dflow_bs,
-                                                          int H, int W) {
+                                                          int H, int W, int tiles_x) {
   typedef typename FragOf<T>::type FragT;
-  const int n = blockIdx.y;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int p = idx / 3, chunk = idx - p * 3;
-  if (p >= H * W) return;
-  const int sy = p / W, sx = p - sy * W;
-  int rw = 1;
+  typedef C3WarpBwd B;
+  __shared__ int2 tap_xy[B::NCAND];                  // (x0, y0) of every candidate output pixel; x0 = INT_MIN: outside the image
+  __shared__ float2 tap_w[B::NCAND];                 // (wx, wy)
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const int ty0 = (tile / tiles_x) * B::TS, tx0 = (tile % tiles_x) * B::TS;
+  const int sy = ty0 + (int)threadIdx.x / B::TS, sx = tx0 + (int)threadIdx.x % B::TS;
+  int rw = 0;
   if (s.flow) {
     const float b = *flow_bound;
     rw = (b < 0.f ? 0 : (b > 1e6f ? 1000000 : (int)ceilf(b))) + 1;
-  } else {
-    rw = 0;
   }
-  const T* gi = g + (size_t)n * H * W * 32;
-  float acc[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  const int y_lo = sy - rw < 0 ? 0 : sy - rw, y_hi = sy + rw >= H ? H - 1 : sy + rw;
-  const int x_lo = sx - rw < 0 ? 0 : sx - rw, x_hi = sx + rw >= W ? W - 1 : sx + rw;
-  for (int oy = y_lo; oy <= y_hi; ++oy)
-    for (int ox = x_lo; ox <= x_hi; ++ox) {
-      const WarpTaps t = c3_taps_of(s.flow, s.flow_bs, n, oy, ox, H, W);
-      const int dy = sy - t.y0, dx = sx - t.x0;
-      if (dy < 0 || dy > 1 || dx < 0 || dx > 1) continue;
-      const float wgt = (dx ? t.wx : 1.f - t.wx) * (dy ? t.wy : 1.f - t.wy);
-      // state channels 8 chunk .. +7 sit at g channels 3 + 8 chunk ..: two aligned chunks, shifted by 3
-      const T* row = gi + ((size_t)oy * W + ox) * 32 + chunk * 8;
-      const FragT a = *reinterpret_cast<const FragT*>(row), b = *reinterpret_cast<const FragT*>(row + 8);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += wgt * (float)(j < 5 ? a[3 + j] : b[j - 5]);
+  const bool in_lds = rw <= B::RW_LDS;                // uniform over the grid
+  const int cw = B::TS + 2 * rw;
+  if (in_lds) {                                      // every candidate's taps once per workgroup (two IEEE divisions each)
+    for (int i = threadIdx.x; i < cw * cw; i += 256) {
+      const int oy = ty0 - rw + i / cw, ox = tx0 - rw + i % cw;
+      int2 xy = {INT_MIN, 0};
+      float2 wq = {0.f, 0.f};
+      if (oy >= 0 && oy < H && ox >= 0 && ox < W) {
+        const WarpTaps t = c3_taps_of(s.flow, s.flow_bs, n, oy, ox, H, W);
+        xy.x = t.x0; xy.y = t.y0; wq.x = t.wx; wq.y = t.wy;
+      }
+      tap_xy[i] = xy;
+      tap_w[i] = wq;
     }
-  FragT o;
+    __syncthreads();
+  }
+  const bool live = sy < H && sx < W;
+  const int p = sy * W + sx;
+  const T* gi = g + (size_t)n * H * W * 32;
+  float acc[C3Cfg::CO];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (T)acc[j];
-  *reinterpret_cast<FragT*>(dstate + ((size_t)n * H * W + p) * C3Cfg::CO + chunk * 8) = o;
+  for (int j = 0; j < C3Cfg::CO; ++j) acc[j] = 0.f;
+  if (live) {
+    const int y_lo = sy - rw < 0 ? 0 : sy - rw, y_hi = sy + rw >= H ? H - 1 : sy + rw;
+    const int x_lo = sx - rw < 0 ? 0 : sx - rw, x_hi = sx + rw >= W ? W - 1 : sx + rw;
+    for (int oy = y_lo; oy <= y_hi; ++oy)
+      for (int ox = x_lo; ox <= x_hi; ++ox) {
+        int x0, y0;
+        float wx, wy;
+        if (in_lds) {
+          const int i = (oy - (ty0 - rw)) * cw + ox - (tx0 - rw);
+          x0 = tap_xy[i].x; y0 = tap_xy[i].y; wx = tap_w[i].x; wy = tap_w[i].y;
+        } else {
+          const WarpTaps t = c3_taps_of(s.flow, s.flow_bs, n, oy, ox, H, W);
+          x0 = t.x0; y0 = t.y0; wx = t.wx; wy = t.wy;
+        }
+        const int dy = sy - y0, dx = sx - x0;
+        if (dy < 0 || dy > 1 || dx < 0 || dx > 1) continue;
+        const float wgt = (dx ? wx : 1.f - wx) * (dy ? wy : 1.f - wy);
+        // state channel c sits at g channel 3 + c: the 64-byte row as four aligned chunks, shifted by 3
+        const T* row = gi + ((size_t)oy * W + ox) * 32;
+        FragT q[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[c] = *reinterpret_cast<const FragT*>(row + c * 8);
+#pragma unroll
+        for (int j = 0; j < C3Cfg::CO; ++j) acc[j] += wgt * (float)q[(3 + j) >> 3][(3 + j) & 7];
+      }
+#pragma unroll
+    for (int c = 0; c < C3Cfg::COC; ++c) {
+      FragT o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (T)acc[c * 8 + j];
+      *reinterpret_cast<FragT*>(dstate + ((size_t)n * H * W + p) * C3Cfg::CO + c * 8) = o;
+    }
+  }
+  if (!live) return;
 
-  if (dflow && chunk == 0) {                         // this thread's pixel as an OUTPUT pixel
+  if (dflow) {                                       // this thread's pixel as an OUTPUT pixel
     float gx = 0.f, gy = 0.f;
     if (s.state && s.flow) {
       const WarpTaps t = c3_taps_of(s.flow, s.flow_bs, n, sy, sx, H, W);

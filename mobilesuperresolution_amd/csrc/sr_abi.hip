@@ -371,7 +371,7 @@ inline C3Grid c3_grid(int N, int H, int W) {
 }
 template <typename T> C3WarpSrc<T> c3_warp_src(const sr_c3_warp_t* w) {
   C3WarpSrc<T> s{};
-  if (w) { s.frame = w->frame; s.state = (const T*)w->state; s.flow = w->flow; s.frame_bs = w->frame_bs; s.flow_bs = w->flow_bs; }
+  if (w) { s.frame = w->frame; s.state = (const T*)w->state; s.flow = w->flow; s.frame_bs = w->frame_bs; s.flow_bs = w->flow_bs; s.x0_save = (T*)w->x0_save; }
   return s;
 }
 template <typename T>
@@ -502,13 +502,14 @@ static int c3_trunk_bwd_t(const void* x0, const sr_c3_warp_t* warp, const void* 
     if ((rc = c3_wgrad_t<T>(acts, gt, mids, parts + slot, wgs, N, H, W, 24, 1, st, nb, (long)act, (long)act, (long)act, 2 * slot)))
       return rc;
   }
-  if ((rc = c3_wgrad_t<T>(x0, ga, acts, parts, wgs, N, H, W, ci0, 2, st, 1, 0, 0, 0, 0, warp))) return rc;
+  const bool regather = warp && !warp->x0_save;      // the forward kept the gathered input unless told not to
+  if ((rc = c3_wgrad_t<T>(warp && !regather ? warp->x0_save : x0, ga, acts, parts, wgs, N, H, W, ci0, 2, st, 1, 0, 0, 0, 0, regather ? warp : nullptr))) return rc;
   if (dx0 && (rc = c3_bwd_t<T>(ga, acts, nullptr, dx0, blob + boff[0], N, H, W, ci0, 2, st))) return rc;
   if (warp && (warp->dstate || warp->dflow)) {       // flow_warp backward, gather form (no float atomics)
     if (!dx0 || !warp->dstate || (warp->flow && !warp->flow_bound)) return -2;
-    const int threads = H * W * 3;
-    hipLaunchKernelGGL((c3_warp_bwd_kernel<T>), dim3((threads + 255) / 256, N), dim3(256), 0, st, (const T*)dx0, c3_warp_src<T>(warp),
-                       warp->flow_bound, (T*)warp->dstate, warp->dflow, warp->dflow_bs, H, W);
+    const int tx = (W + C3WarpBwd::TS - 1) / C3WarpBwd::TS, ty = (H + C3WarpBwd::TS - 1) / C3WarpBwd::TS;
+    hipLaunchKernelGGL((c3_warp_bwd_kernel<T>), dim3(tx * ty, N), dim3(256), 0, st, (const T*)dx0, c3_warp_src<T>(warp),
+                       warp->flow_bound, (T*)warp->dstate, warp->dflow, warp->dflow_bs, H, W, tx);
     SR_HIP_CHECK_LAUNCH();
   }
   if (up) {                                          // slabs -> gradient of the flat parameter

@@ -116,17 +116,22 @@ class WDSRLayout:
         dst_a = np.concatenate([ob["w1"] + np.arange(n_w1), ob["w2"] + np.arange(n_w2),
                                 ob["b1"] + np.arange(E), ob["b2"] + np.arange(L)])
         dst_b = np.concatenate([ob["w3"] + np.arange(n_w3), ob["b3"] + np.arange(F)])
-        self.ga = (ga.astype(np.int32), dst_a.astype(np.int32))
-        self.gb = (gb.astype(np.int32), dst_b.astype(np.int32))
+        def by_slab(sidx, dst):
+            """in slab order: the reduction kernel then READS each of the many partial slabs in runs (coalesced) and
+            scatters only its one result per element"""
+            o = np.argsort(sidx, kind="stable")
+            return sidx[o].astype(np.int32), dst[o].astype(np.int32)
+        self.ga = by_slab(ga, dst_a)
+        self.gb = by_slab(gb, dst_b)
         self.slab_a, self.slab_b = gt["a_size"], gt["b_size"]
         ge = P.ends_grad_tables(F, R)
         n_t = CO * F * 9 + CO * 75 + CO
         dst_t = np.concatenate([ot["wt"] + np.arange(CO * F * 9), ot["ws"] + np.arange(CO * 75),
                                 ot["b"] + np.arange(CO)])
         assert ge["tail"].size == n_t
-        self.gt = (ge["tail"].astype(np.int32), dst_t.astype(np.int32))
+        self.gt = by_slab(ge["tail"], dst_t)
         dst_h = np.concatenate([oh["wh"] + np.arange(F * 27), oh["b"] + np.arange(F)])
-        self.gh = (ge["head"].astype(np.int32), dst_h.astype(np.int32))
+        self.gh = by_slab(ge["head"], dst_h)
         self.slab_tail, self.slab_head = ge["tail_size"], ge["head_size"]
 
 

@@ -81,9 +81,10 @@ def _unpack_tables(cin: int, device_index: int):
     """int32 tables for the slab -> flat-gradient reduction inside sr_c3_trunk_bwd: (sidx0, dst0, sidx1, dst1)"""
     dev = torch.device("cuda", device_index)
 
-    def mk(t):
-        g = t["grad"].astype(np.int32)
-        return torch.from_numpy(g).to(dev), torch.arange(len(g), dtype=torch.int32, device=dev)
+    def mk(t):                                       # in slab order: coalesced reads of the 64 partial slabs, scattered result
+        g = t["grad"].astype(np.int64)
+        o = np.argsort(g, kind="stable")
+        return torch.from_numpy(g[o].astype(np.int32)).to(dev), torch.from_numpy(o.astype(np.int32)).to(dev)
     return mk(P.c3_tables(cin)) + mk(P.c3_tables(24))
 
 
@@ -323,14 +324,16 @@ class _TrunkWarpFunction(torch.autograd.Function):
             tabs = _trunk_tables(27, nb, dev.index)
             acts = torch.empty((nb + 1, n, h, w, 24), dtype=dt, device=dev)
             mids = torch.empty((max(nb, 1), n, h, w, 24), dtype=dt, device=dev)
+            # the gathered input is kept (2 MB at C4) when a backward will want the first conv's weight gradient
+            x0 = torch.empty((n, h, w, 32), dtype=dt, device=dev) if ctx.needs_input_grad[5] else None
             warp = L.C3Warp(frame_.data_ptr(), frame_.stride(0), state_.data_ptr() if state_ is not None else None,
                             flow_.data_ptr() if flow_ is not None else None, flow_.stride(0) if flow_ is not None else 0,
-                            None, None, None, 0)
+                            None, None, None, 0, x0.data_ptr() if x0 is not None else None)
             _launch("sr_c3_trunk_fwd", None, ctypes.byref(warp), acts.data_ptr(), mids.data_ptr(), blob.data_ptr(), tabs[2], nb,
                     n, h, w, 32, L.DTYPE_CODE[dt])
             out = torch.empty((n, mod.num_feat, h, w), dtype=torch.float32, device=dev)
             out.copy_(acts[nb][..., :mod.num_feat].permute(0, 3, 1, 2))
-        ctx.mod, ctx.acts, ctx.mids, ctx.blob = mod, acts, mids, blob
+        ctx.mod, ctx.acts, ctx.mids, ctx.blob, ctx.x0 = mod, acts, mids, blob, x0
         ctx.frame, ctx.state, ctx.flow, ctx.bound = frame_, state_, flow_, bound_
         ctx.need = (frame.requires_grad, state is not None and state.requires_grad, flow is not None and flow.requires_grad)
         ctx.set_materialize_grads(False)
@@ -376,7 +379,8 @@ class _TrunkWarpFunction(torch.autograd.Function):
                             flow.data_ptr() if flow is not None else None, flow.stride(0) if flow is not None else 0,
                             bound.data_ptr() if bound is not None else None,
                             dstate.data_ptr() if dstate is not None else None,
-                            dflow.data_ptr() if dflow is not None else None, 2 * h * w)
+                            dflow.data_ptr() if dflow is not None else None, 2 * h * w,
+                            ctx.x0.data_ptr() if ctx.x0 is not None else None)
             total = s0.numel() + 2 * nb * s1.numel()
             gflat = torch.empty(total, dtype=torch.float32, device=dev)
             unpack = L.C3Unpack(s0.data_ptr(), d0.data_ptr(), s0.numel(), s1.data_ptr(), d1.data_ptr(), s1.numel(), gflat.data_ptr())
@@ -387,6 +391,16 @@ class _TrunkWarpFunction(torch.autograd.Function):
             if mod._pad:
                 gflat = gflat.index_select(0, mod._unpad_idx)
         return dframe, (dstate if need_state else None), dflow, None, None, gflat
+
+
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
 
 
 def _fusable(trunk):
@@ -404,14 +418,27 @@ def propagate(x, flows_forward, flows_backward, backward_trunk, forward_trunk, f
         bound = None
         if n > 1:
             bound = torch.maximum(flows_forward.detach().abs().amax(), flows_backward.detach().abs().amax())
-        state = None
-        for i in range(n - 1, -1, -1):
-            feat, state = backward_trunk.forward_warped(x[:, i], state, flows_backward[:, i] if i < n - 1 else None, bound)
-            out_b.insert(0, feat)
+        # The two directions are independent recurrences and one of them fills barely half of the chip (144 workgroups at
+        # 8 clips of 64x64): the backward-time loop runs on a side stream, the forward-time loop on the caller's; autograd
+        # replays each node's backward on the stream its forward ran on.  Opt-in (SR_VSR_TWO_STREAMS=1): at C4 the step is bound
+        # by host issue, and the stream switches cost more host time (2.24 -> 2.63 ms) than the overlap returns.
+        cur = torch.cuda.current_stream(x.device)
+        side = _side_stream(x.device) if os.environ.get("SR_VSR_TWO_STREAMS", "0") == "1" else cur
+        if side is not cur:
+            side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            state = None
+            for i in range(n - 1, -1, -1):
+                feat, state = backward_trunk.forward_warped(x[:, i], state, flows_backward[:, i] if i < n - 1 else None, bound)
+                out_b.insert(0, feat)
         state = None
         for i in range(n):
             feat, state = forward_trunk.forward_warped(x[:, i], state, flows_forward[:, i - 1] if i > 0 else None, bound)
             out_f.append(feat)
+        if side is not cur:
+            cur.wait_stream(side)
+            for t in out_b:
+                t.record_stream(cur)                 # allocated on the side stream, consumed on the caller's
         return out_b, out_f
     feat = x.new_zeros(b, num_feat, h, w)
     for i in range(n - 1, -1, -1):
