@@ -189,6 +189,13 @@ int sr_c3_trunk_bwd(const void* x0, const sr_c3_warp_t* warp, const void* acts, 
                     const void* blob, const long* blob_off, float* parts, void* dx0, const sr_c3_unpack_t* unpack, int nb,
                     int wgs, int N, int H, int W, int ci0, int dtype, sr_stream_t stream);
 
+/* Evaluation metrics on device: psnr (luma = 0; common/metrics.py:10-19: 8-bit quantised sr) and psnr_y (luma = 1 for
+ * 3-channel images; :22-38: clamped but NOT quantised -- the reference drops its quantised copy -- with the luma filter
+ * on the difference; luma = -1: the same without the filter, what the reference does when dim 1 is not 3).  sr, hr
+ * [N][C][H][W] fp32; partial [N * wgs] scratch; out[0] = sum over the batch of -10 log10(mse) (the reference sums). */
+int sr_psnr(const float* sr, const float* hr, float* partial, float* out, int N, int C, int H, int W, int shave, int luma,
+            int wgs, sr_stream_t stream);
+
 /* flow_warp, models/spynet_arch.py:98-129 (bilinear, zeros padding, align_corners=True): x, out NCHW fp32;
  * flow (N,H,W,2).  Backward: dx (zero-filled by the caller, may be NULL) and dflow (may be NULL). */
 int sr_flow_warp_fwd(const float* x, const float* flow, float* out, int N, int C, int H, int W, sr_stream_t stream);

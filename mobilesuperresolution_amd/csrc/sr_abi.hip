@@ -9,6 +9,7 @@
 #include "conv3x3.h"
 #include "nas_block.h"
 #include "flow_warp.h"
+#include "metrics.h"
 #include "train_step.h"
 #include "pixel_shuffle.h"
 
@@ -877,6 +878,26 @@ extern "C" int sr_pixel_shuffle(const float* in, float* out, int N, int C, int H
     hipLaunchKernelGGL((pixel_shuffle_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, C, H, W, r, total4);
   else
     hipLaunchKernelGGL((pixel_shuffle_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, C, H, W, r, total4);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// evaluation metrics
+// ------------------------------------------------------------------------------------------
+extern "C" int sr_psnr(const float* sr, const float* hr, float* partial, float* out, int N, int C, int H, int W, int shave,
+                       int luma, int wgs, sr_stream_t stream) {
+  if (!sr || !hr || !partial || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || shave < 0 || wgs <= 0 || N > 65535 ||
+      (luma && C != 3 && luma != -1))
+    return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(wgs, N);
+  if (luma == 1) hipLaunchKernelGGL((sr_sqdiff_kernel<1>), grid, dim3(256), 0, st, sr, hr, partial, C, H, W, shave);
+  else if (luma == -1) hipLaunchKernelGGL((sr_sqdiff_kernel<-1>), grid, dim3(256), 0, st, sr, hr, partial, C, H, W, shave);
+  else hipLaunchKernelGGL((sr_sqdiff_kernel<0>), grid, dim3(256), 0, st, sr, hr, partial, C, H, W, shave);
+  const long hs = H - 2 * shave, ws = W - 2 * shave;
+  const double count = (hs > 0 && ws > 0) ? (double)hs * ws * (luma == 1 ? 1 : C) : 0.0;
+  hipLaunchKernelGGL(sr_psnr_finish_kernel, dim3(1), dim3(64), 0, st, partial, out, N, wgs, count);
   SR_HIP_CHECK_LAUNCH();
   return 0;
 }

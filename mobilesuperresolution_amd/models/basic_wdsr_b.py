@@ -345,6 +345,11 @@ class BASIC_MODEL(nn.Module):
                                       "loss (DistributedDataParallel hooks need the two gradient nodes)")
         return _NetLossFunction.apply(x, hr, self.flat, self, kind, float(weight))
 
+    def receptive_halo(self) -> int:
+        """LR pixels of context an output pixel depends on, per side: head 3x3 + one 3x3 per block + tail 3x3 (the 5x5 skip
+        needs 2) -- what a tile of inference.tiled_forward must carry around its core"""
+        return self.num_blocks + 2
+
     def ddp_bucket_cap_mb(self) -> float:
         """`bucket_cap_mb` for DistributedDataParallel such that each gradient segment is its own bucket (two-segment
         mode): DDP closes a bucket once it has reached the cap, so the cap is half the smaller segment."""

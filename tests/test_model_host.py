@@ -40,3 +40,35 @@ def test_cpu_tensors_and_device_mismatch_raise():
     # exercise the check directly: x on cuda:0, parameters on cuda:1
     with pytest.raises(L.HotpathError, match="different devices"):
         type(m)._check_input(type("M", (), {"flat": flat})(), x)
+
+
+def test_window_plan_covers_every_pixel_once_with_halo():
+    """inference.window_plan: cores partition the image; every window edge that is not the image border is at least
+    `halo` away from the core it serves"""
+    from mobilesuperresolution_amd.inference import window_plan
+    for (h, w, tile, halo) in [(70, 93, 32, 6), (48, 200, (48, 64), 18), (31, 37, 16, 6), (40, 40, 64, 6), (512, 340, 96, 18),
+                               (37, 37, 1, 3)]:
+        wh, ww, plan = window_plan(h, w, tile, halo)
+        cover = [[0] * w for _ in range(h)]
+        for (oy, ox, y0, y1, x0, x1) in plan:
+            assert 0 <= oy and oy + wh <= h and 0 <= ox and ox + ww <= w
+            assert oy <= y0 < y1 <= oy + wh and ox <= x0 < x1 <= ox + ww
+            assert oy == 0 or y0 - oy >= halo
+            assert oy + wh == h or oy + wh - y1 >= halo
+            assert ox == 0 or x0 - ox >= halo
+            assert ox + ww == w or ox + ww - x1 >= halo
+            for y in range(y0, y1):
+                for x in range(x0, x1):
+                    cover[y][x] += 1
+        assert all(v == 1 for row in cover for v in row)
+
+
+def test_metrics_refuse_cpu_tensors():
+    import pytest
+    import torch
+    from mobilesuperresolution_amd import _lib as L
+    from mobilesuperresolution_amd.metrics import psnr, psnr_y
+    a = torch.rand(1, 3, 16, 16)
+    for fn in (psnr, psnr_y):
+        with pytest.raises(L.HotpathError):
+            fn(a, a)
