@@ -189,6 +189,20 @@ int sr_c3_trunk_bwd(const void* x0, const sr_c3_warp_t* warp, const void* acts, 
                     const void* blob, const long* blob_off, float* parts, void* dx0, const sr_c3_unpack_t* unpack, int nb,
                     int wgs, int N, int H, int W, int ci0, int dtype, sr_stream_t stream);
 
+/* Training patches cut on device from a resident uint8 cache.  Replaces, per patch,
+ * ImageSuperResolutionDataset._sample_patch + _augment + to_tensor, datasets/_isr.py:68-121.  cache: every LR and HR image
+ * as PIL lays them out (H x W x 3 uint8), back to back; recs[B]: one record per patch, drawn on the host in the
+ * reference's RNG order; lr_out [B][3][P][P], hr_out [B][3][P*scale][P*scale] fp32 in [0, 1] (either may be NULL). */
+typedef struct sr_patch_rec {
+  long lr_off, hr_off;      /* byte offsets of the two images in the cache */
+  int lr_w, hr_w;           /* their widths in pixels */
+  int x, y;                 /* LR crop origin: row x, column y (the reference's names) */
+  int flags;                /* 1: flip rows, 2: flip columns, 4: swap axes -- applied in this order */
+  int pad_;
+} sr_patch_rec_t;
+int sr_patch_gather(const unsigned char* cache, const void* recs, float* lr_out, float* hr_out, int B, int P, int scale,
+                    sr_stream_t stream);
+
 /* Evaluation metrics on device: psnr (luma = 0; common/metrics.py:10-19: 8-bit quantised sr) and psnr_y (luma = 1 for
  * 3-channel images; :22-38: clamped but NOT quantised -- the reference drops its quantised copy -- with the luma filter
  * on the difference; luma = -1: the same without the filter, what the reference does when dim 1 is not 3).  sr, hr

@@ -52,6 +52,7 @@ SIGNATURES = {
     "sr_nas_pw_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "sr_nas_pw_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_nas_dw_bwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
+    "sr_patch_gather": ([_P, _P, _P, _P, _I, _I, _I, _P], _I),
     "sr_psnr": ([_P, _P, _P, _P] + [_I] * 7 + [_P], _I),
     "sr_pixel_shuffle": ([_P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_tail_bwd_loss": ([_P, _P, _I, _F, _P, _P, _P, _F, _P, _P, _P] + [_I] * 7 + [_P], _I),

@@ -10,6 +10,7 @@
 #include "nas_block.h"
 #include "flow_warp.h"
 #include "metrics.h"
+#include "patches.h"
 #include "train_step.h"
 #include "pixel_shuffle.h"
 
@@ -878,6 +879,26 @@ extern "C" int sr_pixel_shuffle(const float* in, float* out, int N, int C, int H
     hipLaunchKernelGGL((pixel_shuffle_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, C, H, W, r, total4);
   else
     hipLaunchKernelGGL((pixel_shuffle_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, C, H, W, r, total4);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// input pipeline
+// ------------------------------------------------------------------------------------------
+extern "C" int sr_patch_gather(const unsigned char* cache, const void* recs, float* lr_out, float* hr_out, int B, int P, int scale,
+                               sr_stream_t stream) {
+  static_assert(sizeof(PatchRec) == 40, "record layout is part of the ABI (sr_patch_rec_t)");
+  if (!cache || !recs || (!lr_out && !hr_out) || B <= 0 || B > 65535 || P <= 0 || scale <= 0) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  if (lr_out) {
+    const int blocks = std::min((3 * P * P + 255) / 256, 64);
+    hipLaunchKernelGGL(sr_patch_gather_kernel, dim3(blocks, B), dim3(256), 0, st, cache, (const PatchRec*)recs, lr_out, P, scale, 0);
+  }
+  if (hr_out) {
+    const int S = P * scale, blocks = std::min((3 * S * S + 255) / 256, 256);
+    hipLaunchKernelGGL(sr_patch_gather_kernel, dim3(blocks, B), dim3(256), 0, st, cache, (const PatchRec*)recs, hr_out, P, scale, 1);
+  }
   SR_HIP_CHECK_LAUNCH();
   return 0;
 }

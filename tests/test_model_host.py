@@ -72,3 +72,29 @@ def test_metrics_refuse_cpu_tensors():
     for fn in (psnr, psnr_y):
         with pytest.raises(L.HotpathError):
             fn(a, a)
+
+
+def test_patch_oracle_shapes_and_flip_order():
+    """oracle/patch_oracle.py restates datasets/_isr.py:87-121: crop, then row flip, column flip, axis swap, then to_tensor"""
+    import random
+    import numpy as np
+    from oracle import patch_oracle as PO
+
+    class Fixed:
+        def __init__(self, ints, floats):
+            self.ints, self.floats = list(ints), list(floats)
+
+        def randrange(self, a, b):
+            v = self.ints.pop(0)
+            assert a <= v < b
+            return v
+
+        def random(self):
+            return self.floats.pop(0)
+    lr = np.arange(10 * 12 * 3, dtype=np.uint8).reshape(10, 12, 3)
+    hr = np.arange(20 * 24 * 3, dtype=np.uint8).reshape(20, 24, 3)
+    l, h = PO.train_item([lr], [hr], 0, 4, 2, 1, 1, Fixed([3, 5], [0.1, 0.9, 0.2]))       # row flip, no column flip, swap
+    assert l.shape == (3, 4, 4) and h.shape == (3, 8, 8) and l.dtype == np.float32
+    crop = lr[3:7, 5:9][::-1]
+    assert np.array_equal(l, np.swapaxes(crop, 0, 1).transpose(2, 0, 1).astype(np.float32) / np.float32(255))
+    assert h[0, 0, 0] == np.float32(hr[13, 10, 0]) / np.float32(255)                        # HR crop rows 6..13 flipped -> first is row 13
