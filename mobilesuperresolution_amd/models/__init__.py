@@ -55,9 +55,9 @@ def wrap_ddp(model, **ddp_kwargs):
     two things the hot path needs that stock defaults do not give:
       * BASIC_MODEL with two gradient segments: a bucket cap that separates the segments, so that the late half's
         all-reduce runs under the early half's backward (bucket_cap_mb, gradient_as_bucket_view);
-      * NAS_MODEL: `beta`, `beta1`, `beta2` are frozen first (NAS_MODEL.freeze_gradless_parameters) -- they never receive
-        gradients and DDP without find_unused_parameters raises on them.  Freezing was chosen over
-        find_unused_parameters=True, which walks the autograd graph and synchronises with the host every iteration.
+      * NAS_MODEL: nothing -- the reference's `beta`, `beta1`, `beta2` (Parameters that never receive a gradient, on which
+        DDP without find_unused_parameters raises) are slices of the model's one flat body parameter here, with a zero
+        gradient, so neither freezing nor find_unused_parameters=True (a graph walk and a host sync per iteration) is needed.
     Call it again after each phase change of search.py:329-333,372-376 (unwrap with `.module`, length_grad / mask_grad,
     wrap_ddp)."""
     from torch.nn.parallel import DistributedDataParallel as DDP

@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import math
 import os
-from collections import namedtuple
+from collections import OrderedDict, namedtuple
 from functools import lru_cache
 
 import numpy as np
@@ -416,7 +416,86 @@ class _TailFunction(torch.autograd.Function):
         return dfeat, None, g[:nt].view(ctx.shapes[0]), g[nt:nt + ns].view(ctx.shapes[1]), g[nt + ns:nt + ns + co], None, None
 
 
+def _body_kinds(f: int):
+    """(reference key suffix, per-block shape) of every tensor a MyAggregationLayer owns, in the reference's state_dict order
+    (wdsr_b.py:419-431,375-402,505-515)"""
+    kinds = [("alpha", (3,)), ("beta", (3,)), ("alpha1", (1,)), ("beta1", (1,)), ("alpha2", (1,)), ("beta2", (1,)),
+             ("split.weight", (f, 1, 1, 1))]
+    for k in (3, 5, 7):
+        kinds += [(f"body.{k}.0.body.0.bias", (f,)), (f"body.{k}.0.body.0.weight_g", (f, 1, 1, 1)),
+                  (f"body.{k}.0.body.0.weight_v", (f, 1, k, k)), (f"body.{k}.0.body.2.bias", (f,)),
+                  (f"body.{k}.0.body.2.weight_g", (f, 1, 1, 1)), (f"body.{k}.0.body.2.weight_v", (f, f, 1, 1))]
+    return kinds
+
+
+class _SplitFlat(torch.autograd.Function):
+    """flat body parameter -> one (nb, ...) tensor per kind.  Forward is ONE copy (the kinds are slices of it: later in-place
+    writes into the parameter -- forward() rewrites beta1 / beta2 like the reference, :534 -- cannot disturb what autograd
+    saved); backward is ONE cat.  `frozen`: kinds whose gradient is zeroed (length_grad / mask_grad / kernel_grad(False))."""
+
+    @staticmethod
+    def forward(ctx, flat, layout, frozen):
+        ctx.layout, ctx.frozen = layout, frozen
+        snap = flat.detach().clone()
+        outs = tuple(snap[o:o + n].view(shape) for (_, o, n, shape) in layout)
+        ctx.mark_non_differentiable(*[t for t, (name, *_r) in zip(outs, layout) if name in frozen])
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        dev = next(g.device for g in grads if g is not None)
+        zeros = {}
+        parts = []
+        for g, (name, o, n, shape) in zip(grads, ctx.layout):
+            if g is None or name in ctx.frozen:
+                if n not in zeros:
+                    zeros[n] = torch.zeros(n, dtype=torch.float32, device=dev)
+                parts.append(zeros[n])
+            else:
+                parts.append(g.reshape(-1))
+        return torch.cat(parts), None, None
+
+
+class _Holder:
+    """attribute bag of a block view"""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class _BlockView:
+    """`model.body[i]` of the reference, as views into the flat body parameter: .alpha, .beta, .alpha1, .beta1, .alpha2,
+    .beta2, .split.weight, .body['3'][0].body[0].{bias, weight_g, weight_v} ...  Reads and in-place writes (under no_grad)
+    go straight to the parameter."""
+
+    def __init__(self, model, i):
+        self._m, self._i = model, i
+
+    def _t(self, suffix):
+        return self._m.kind(suffix)[self._i]
+
+    def __getattr__(self, name):
+        if name in ("alpha", "beta", "alpha1", "beta1", "alpha2", "beta2"):
+            return self._t(name)
+        if name == "split":
+            return _Holder(weight=self._t("split.weight"))
+        if name == "body":
+            return {str(k): [_Holder(body=[_Holder(**{n: self._t(f"body.{k}.0.body.0.{n}") for n in ("bias", "weight_g", "weight_v")}),
+                                           None,
+                                           _Holder(**{n: self._t(f"body.{k}.0.body.2.{n}") for n in ("bias", "weight_g", "weight_v")})])]
+                    for k in (3, 5, 7)}
+        raise AttributeError(name)
+
+    def _skipped(self) -> bool:
+        return bool(self._m._skip_flags()[self._i])
+
+
 class NAS_MODEL(nn.Module):
+    """Parameters: head / tail / skip (weight-normalised convs, 3 tensors each), mask.weight, and ONE flat fp32 parameter
+    `flat` that holds every tensor of the 16 search blocks, stacked over blocks kind by kind.  With one tensor per
+    reference key (25 per block, 400 at C5) a training step spent most of its 5.4 ms in autograd's per-tensor
+    bookkeeping, `cat` / `stack` backward splits and a 362-tensor Adam; the reference keys live on as views
+    (`state_dict()` / `load_state_dict()` / `named_reference_tensors()` / `body[i].alpha1` ...)."""
 
     def __init__(self, params):
         super().__init__()
@@ -437,11 +516,23 @@ class NAS_MODEL(nn.Module):
                                       "(forward uses self.mask); construct it with width_search=True")
         self.hot_dtype = _hot_dtype(params)
         nout = self.scale * self.scale * nin
+        nb = self.num_blocks
         self.head = _WNConv(nin, f, 3, g_init=1.0, zero_bias=True)
         self.speed_estimator = BlockBSpeedEstimator("mask" if params.width_search else "channel").eval()
-        self.body = nn.ModuleList([MyAggregationLayer(num_residual_units=f, kernel_size=3,
-                                                      res_scale=1 / math.sqrt(self.num_blocks), width_search=True)
-                                   for _ in range(self.num_blocks)])
+        # the reference's constructor calls, in the reference's order (same RNG draws), then laid out kind by kind
+        blocks = [MyAggregationLayer(num_residual_units=f, kernel_size=3, res_scale=1 / math.sqrt(nb), width_search=True)
+                  for _ in range(nb)]
+        self._layout, off, vals = [], 0, []
+        for suffix, shape in _body_kinds(f):
+            n = nb * int(np.prod(shape))
+            self._layout.append((suffix, off, n, (nb,) + tuple(shape)))
+            vals.append(torch.stack([dict(b.named_parameters())[suffix].detach() for b in blocks]).reshape(-1).float())
+            off += n
+        self._layout = tuple(self._layout)
+        self._kind_index = {name: i for i, (name, *_r) in enumerate(self._layout)}
+        self.flat = nn.Parameter(torch.cat(vals))
+        self._frozen = frozenset()
+        self.body = [_BlockView(self, i) for i in range(nb)]          # views, not modules: nothing to register
         self.mask = BinaryConv2d(in_channels=f, out_channels=f, groups=f)
         self.tail = _WNConv(f, nout, 3, g_init=1.0, zero_bias=True)
         self.skip = _WNConv(nin, nout, 5, g_init=1.0, zero_bias=True)        # bare conv in NAS_MODEL: keys skip.*
@@ -449,13 +540,74 @@ class NAS_MODEL(nn.Module):
         if getattr(params, "pretrained", False):
             self.load_pretrained(getattr(params, "pretrained_path", None))
 
+    # ---- the reference's tensors as views ----
+    def kind(self, suffix, source=None):
+        """(nb, ...) view of one kind (e.g. 'alpha1', 'body.5.0.body.2.weight_v') over the flat parameter, or over any
+        tensor laid out like it (its gradient)"""
+        _, o, n, shape = self._layout[self._kind_index[suffix]]
+        base = self.flat.detach() if source is None else source
+        return base[o:o + n].view(shape)
+
+    def named_reference_tensors(self, grads=False):
+        """(reference state_dict key, tensor) in the reference's order: head.*, speed_estimator.*, body.{i}.*, mask.weight,
+        tail.*, skip.*.  grads=True: the gradients instead (None where there is none)."""
+        def own(prefix, mod):
+            for n, p in mod.named_parameters():
+                yield prefix + n, (p.grad if grads else p.detach())
+        yield from own("head.", self.head)
+        yield from own("speed_estimator.", self.speed_estimator)
+        g = self.flat.grad
+        for i in range(self.num_blocks):
+            for suffix, *_r in self._layout:
+                if grads:
+                    yield f"body.{i}.{suffix}", (None if g is None else self.kind(suffix, g)[i])
+                else:
+                    yield f"body.{i}.{suffix}", self.kind(suffix)[i]
+        yield "mask.weight", (self.mask.weight.grad if grads else self.mask.weight.detach())
+        yield from own("tail.", self.tail)
+        yield from own("skip.", self.skip)
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        if destination is None:
+            destination = OrderedDict()
+        for k, v in self.named_reference_tensors():
+            destination[prefix + k] = v
+        return destination
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        mine = dict(self.named_reference_tensors())
+        with torch.no_grad():
+            for k, view in mine.items():
+                key = prefix + k
+                if key not in state_dict:
+                    missing_keys.append(key)
+                    continue
+                src = state_dict[key]
+                if tuple(src.shape) != tuple(view.shape):
+                    error_msgs.append(f"size mismatch for {key}: checkpoint {tuple(src.shape)} vs model {tuple(view.shape)}")
+                    continue
+                view.copy_(src)
+        for key in list(state_dict):
+            if key.startswith(prefix) and key[len(prefix):] not in mine and key != prefix + "flat":
+                unexpected_keys.append(key)
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        missing, unexpected, errors = [], [], []
+        self._load_from_state_dict(dict(state_dict), "", {}, strict, missing, unexpected, errors)
+        if errors or (strict and (missing or unexpected)):
+            raise RuntimeError("Error(s) in loading state_dict for NAS_MODEL:\n\t" +
+                               "\n\t".join(errors + ([f"Missing key(s): {missing}"] if strict and missing else []) +
+                                           ([f"Unexpected key(s): {unexpected}"] if strict and unexpected else [])))
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
     @torch.no_grad()
     def load_pretrained(self, path=None):
-        """reference wdsr_b.py:235-250: POSITIONAL copy -- walk self.parameters() and take the checkpoint's next tensor
-        whenever the shapes agree (so a BASIC_MODEL checkpoint fills the head and nothing the search blocks own).
-        The reference reads `models/pretrained_weights/wdsr_b_x{scale}_{blocks}_{units}.pt` beside its own file; the same
-        relative location is the default here, `path` (or params.pretrained_path) names the file otherwise.  Loaded with
-        weights_only=True: nothing in the file is executed."""
+        """reference wdsr_b.py:235-250: POSITIONAL copy -- walk the parameters in registration order and take the
+        checkpoint's next tensor whenever the shapes agree (so a BASIC_MODEL checkpoint fills the head and nothing the
+        search blocks own).  The walk is over the reference's tensors (named_reference_tensors), not over this class's
+        flat parameter.  The reference reads `models/pretrained_weights/wdsr_b_x{scale}_{blocks}_{units}.pt` beside its
+        own file; the same relative location is the default here, `path` (or params.pretrained_path) names the file
+        otherwise.  Loaded with weights_only=True: nothing in the file is executed."""
         import os
         if path is None:
             path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pretrained_weights",
@@ -470,38 +622,36 @@ class NAS_MODEL(nn.Module):
         except StopIteration:
             return 0
         taken = 0
-        for p in self.parameters():
-            if p.size() == load_param.size():
-                p.data = load_param.to(device=p.device, dtype=p.dtype)
+        for _, view in self.named_reference_tensors():
+            if view.size() == load_param.size():
+                view.copy_(load_param.to(device=view.device, dtype=view.dtype))
                 taken += 1
                 try:
                     _, load_param = next(items)
                 except StopIteration:
                     pass                              # (the reference keeps comparing against the last tensor, :247-250)
-        self.__dict__.pop("_plist_cache", None)
         return taken
 
     def gradless_parameters(self):
-        """Parameters that are requires_grad=True in the reference yet never receive a gradient from a training forward:
-        every block's `beta` (wdsr_b.py:422, unused) and `beta1`/`beta2` (ConditionFunction.backward returns None for
-        them, :611-616; forward overwrites their .data, :534).  DistributedDataParallel without find_unused_parameters
-        raises on the second iteration when such parameters are registered (SURVEY 8, C5 hazard)."""
-        return [(f"body.{i}.{n}", getattr(m, n)) for i, m in enumerate(self.body) for n in ("beta", "beta1", "beta2")]
+        """The reference registers `beta` (unused, wdsr_b.py:422) and `beta1` / `beta2` (ConditionFunction.backward returns
+        None for them, :611-616) as requires_grad parameters that never receive a gradient: DistributedDataParallel
+        without find_unused_parameters raises on its second iteration over them (SURVEY 8, C5 hazard).  Here they are
+        slices of the flat parameter, whose gradient is simply zero there -- Adam leaves them alone, forward() rewrites
+        beta1 / beta2 -- so there is nothing left to freeze."""
+        return []
 
     def freeze_gradless_parameters(self):
-        """requires_grad=False on gradless_parameters().  Training results are unchanged: the optimizer skips parameters
-        whose grad is None, and beta1/beta2 are (re)written by forward.  Call it AFTER length_grad(), which turns
-        beta1/beta2 back on (:573-577), and BEFORE wrapping in DistributedDataParallel; models.wrap_ddp does both."""
-        names = []
-        for name, p in self.gradless_parameters():
-            if p.requires_grad:
-                p.requires_grad = False
-                names.append(name)
-        return names
+        return []
 
     def forward(self, x):
         if not x.is_cuda:
             raise L.HotpathError("NAS_MODEL (MI355X hot path) needs CUDA/HIP tensors; there is no CPU fallback")
+        if x.device != self.flat.device:
+            raise L.HotpathError(f"input on {x.device}, parameters on {self.flat.device}")
+        with torch.cuda.device(x.device):
+            return self._forward(x)
+
+    def _forward(self, x):
         x = x.contiguous().float()
         f, dt = self.num_residual_units, self.hot_dtype
         y = _HeadFunction.apply(x, self.head.weight(), self.head.bias, f, dt, self.image_mean)
@@ -512,69 +662,59 @@ class NAS_MODEL(nn.Module):
         out = _TailFunction.apply(y, x, self.tail.weight(), self.skip.weight(), btot, self.scale, self.image_mean)
         return out, speed_accu
 
-    def _param_lists(self, idx):
-        """the per-block Parameter objects of blocks `idx`, gathered once (walking ModuleDict / Sequential containers for
-        ~20 tensors x 16 blocks costs more host time per step than the kernels they feed)"""
-        cache = self.__dict__.setdefault("_plist_cache", {})
-        if idx not in cache:
-            blocks = [self.body[i] for i in idx]
-            ks = ("3", "5", "7")
-            cache.clear()
-            cache[idx] = dict(
-                wn={(k, j): ([m.body[k][0].body[j].weight_v for m in blocks], [m.body[k][0].body[j].weight_g for m in blocks])
-                    for k in ks for j in (0, 2)},
-                bdw=[m.body[k][0].body[0].bias for m in blocks for k in ks],
-                bpw=[m.body[k][0].body[2].bias for m in blocks for k in ks],
-                split=[m.split.weight for m in blocks], alpha=[m.alpha for m in blocks],
-                vshape={(k, j): blocks[0].body[k][0].body[j].weight_v.shape for k in ks for j in (0, 2)} if blocks else {})
-        return cache[idx]
+    def _skip_flags(self):
+        """eval-time gates alpha1 >= alpha2 of all blocks as host bools, read back once per parameter version"""
+        key = (self.flat.data_ptr(), self.flat._version)
+        if getattr(self, "_skip_key", None) != key:
+            self._skip_val = (self.kind("alpha1") >= self.kind("alpha2")).reshape(-1).tolist()
+            self._skip_key = key
+        return self._skip_val
 
     def _body(self, y, mg):
         """All MyAggregationLayer blocks (reference wdsr_b.py:111-117 with :517-546 per block) through ONE autograd node:
-        parameters are stacked over blocks so that weight-norm, masks, gates, softmax and the latency terms are a few
-        batched ops, not a few dozen per block.  Returns (y NHWC, speed_accu (1,))."""
-        nball = len(self.body)
-        idx = tuple(range(nball))
-        if not self.training:                       # eval: a skipped block only applies the (idempotent 0/1) global mask
-            idx = tuple(i for i in idx if not self.body[i]._skipped())
-        allp = self._param_lists(tuple(range(nball))) if len(idx) == nball else None
-        if allp is None:
-            allp = dict(split=[m.split.weight for m in self.body], alpha=[m.alpha for m in self.body])
+        weight-norm, masks, gates, softmax and the latency terms are a few batched ops over the stacked kinds.
+        Returns (y NHWC, speed_accu (1,))."""
+        nball, f = self.num_blocks, self.num_residual_units
+        K = dict(zip((name for name, *_r in self._layout), _SplitFlat.apply(self.flat, self._layout, self._frozen)))
         dev = y.device
+        skipped = [] if self.training else self._skip_flags()
+        idx = [i for i in range(nball) if not (skipped and skipped[i])]   # eval: a skipped block only applies the (idempotent 0/1) global mask
         # latency head, reference speed_estimator.py:57-76 (raw alpha, rounding() with its default least_channel = 8)
         with torch.no_grad():
             c_mask = rounding(self.mask.weight.detach()).sum()
-            W = torch.stack(allp["split"]).detach().view(nball, -1)                                 # (NB, F)
+            W = K["split.weight"].detach().view(nball, -1)                                           # (NB, F)
             kth = torch.topk(W, 8, dim=1).values[:, -1:]
             hard = (W >= 0.5).float()
             c_split = torch.where(hard.sum(1, keepdim=True) >= 8, hard, (W >= kth).float()).sum(1)
-            A = torch.stack(allp["alpha"]).detach()                                                 # (NB, 3)
+            A = K["alpha"].detach()                                                                  # (NB, 3)
             speed_curr = ((c_split + 0.2 * c_mask).view(-1, 1) * _const(dev, (9.0, 25.0, 49.0)).view(1, 3) * A / 40).sum(1)
         if self.training:
-            gates = _GateFunction.apply(torch.cat([m.alpha1 for m in self.body]), torch.cat([m.alpha2 for m in self.body]))
+            gates = _GateFunction.apply(K["alpha1"].view(-1), K["alpha2"].view(-1))
             gd = gates.detach()
-            for i, m in enumerate(self.body):                                                       # reference :521-523
-                m.beta1.data, m.beta2.data = gd[i, 0:1], gd[i, 1:2]
+            self.kind("beta1", self.flat.data).copy_(gd[:, 0:1])                                     # reference :521-523,:534
+            self.kind("beta2", self.flat.data).copy_(gd[:, 1:2])
             speed_accu = (gates[:, 1] * speed_curr).sum().reshape(1)
         else:
             gates = None
-            speed_accu = (torch.cat([m.beta2 for m in self.body]) * speed_curr).sum().reshape(1)
+            speed_accu = (K["beta2"].view(-1) * speed_curr).sum().reshape(1)
         if not idx:
             return y, speed_accu
-        pl = self._param_lists(idx)
         nbk = len(idx)
+        if nbk != nball:
+            it = torch.tensor(idx, device=dev)
+            K = {k: v.index_select(0, it) for k, v in K.items()}
 
         def wn(k, j):                                # weight-normalised conv j (0 depthwise, 2 pointwise) of branch k
-            vs, gs = pl["wn"][(k, j)]
-            return torch._weight_norm(torch.cat(vs), torch.cat(gs), 0).view(nbk, *pl["vshape"][(k, j)])
-        WDW = [wn(k, 0) for k in ("3", "5", "7")]
-        WPW = torch.stack([wn(k, 2) for k in ("3", "5", "7")], dim=1)                                # (nb, 3, F, F, 1, 1)
-        BDW = torch.stack(pl["bdw"]).view(nbk, 3, -1)
-        BPW = torch.stack(pl["bpw"]).view(nbk, 3, -1)
-        SW = torch.stack(pl["split"]).view(nbk, -1)                                                 # (nb, F)
+            v, g = K[f"body.{k}.0.body.{j}.weight_v"], K[f"body.{k}.0.body.{j}.weight_g"]
+            return torch._weight_norm(v.reshape(nbk * f, *v.shape[2:]), g.reshape(nbk * f, 1, 1, 1), 0).view(v.shape)
+        WDW = [wn(k, 0) for k in (3, 5, 7)]
+        WPW = torch.stack([wn(k, 2) for k in (3, 5, 7)], dim=1)                                      # (nb, 3, F, F, 1, 1)
+        BDW = torch.stack([K[f"body.{k}.0.body.0.bias"] for k in (3, 5, 7)], dim=1)                  # (nb, 3, F)
+        BPW = torch.stack([K[f"body.{k}.0.body.2.bias"] for k in (3, 5, 7)], dim=1)
+        SW = K["split.weight"].view(nbk, -1)                                                         # (nb, F)
         SWd = SW.detach()
         MS = SW - (SWd - (SWd >= 0.5).float())                   # BinaryConv2d(least_channel=0): value 0/1, gradient 1
-        P = F.softmax(torch.stack(pl["alpha"]), dim=1)
+        P = F.softmax(K["alpha"], dim=1)
         if self.training:
             BETA = gates
         else:
@@ -585,16 +725,12 @@ class NAS_MODEL(nn.Module):
     # ---- search-control surface used by search.py:83-87,292,331-337,374-380 ----
     @torch.no_grad()
     def get_current_blocks(self):
-        return int(sum(1 for m in self.body if m.alpha1 < m.alpha2))
+        return int((self.kind("alpha1") < self.kind("alpha2")).sum())
 
     @torch.no_grad()
     def get_block_status(self):
-        out = []
-        for idx, m in enumerate(self.body):
-            a1, a2 = F.softmax(torch.stack([m.alpha1, m.alpha2], dim=0), dim=0)
-            if a1 < a2:
-                out.append(idx)
-        return out
+        a = F.softmax(torch.stack([self.kind("alpha1"), self.kind("alpha2")], dim=0), dim=0)
+        return [i for i, keep in enumerate((a[0] < a[1]).reshape(-1).tolist()) if keep]
 
     @torch.no_grad()
     def get_width_from_block_idx(self, remain_block_idx):
@@ -610,34 +746,34 @@ class NAS_MODEL(nn.Module):
 
     @torch.no_grad()
     def get_alpha_grad(self):
-        for m in self.body:
-            return m.alpha1.grad, m.alpha2.grad
+        g = self.flat.grad
+        return (None, None) if g is None else (self.kind("alpha1", g)[0], self.kind("alpha2", g)[0])
 
     @torch.no_grad()
     def get_alpha(self):
-        for m in self.body:
-            return m.alpha1, m.alpha2
+        return self.kind("alpha1")[0], self.kind("alpha2")[0]
+
+    def _set_frozen(self, names, frozen):
+        cur = set(self._frozen)
+        cur = (cur | set(names)) if frozen else (cur - set(names))
+        self._frozen = frozenset(cur)
 
     @torch.no_grad()
     def length_grad(self, flag=False):
-        for m in self.body:
-            for p in (m.alpha1, m.alpha2, m.beta1, m.beta2):
-                p.requires_grad = flag
+        """reference :573-577 toggles requires_grad of alpha1 / alpha2 / beta1 / beta2 of every block; here the kinds'
+        gradient slices are zeroed instead (a fresh Adam, as search.py builds after every toggle, then never moves them)"""
+        self._set_frozen(("alpha1", "alpha2", "beta1", "beta2"), not flag)
 
     @torch.no_grad()
     def mask_grad(self, flag=False):
-        for m in self.body:
-            m.split.weight.requires_grad = flag
+        self._set_frozen(("split.weight",), not flag)
         self.mask.weight.requires_grad = flag
 
     @torch.no_grad()
     def kernel_grad(self, flag=False):
-        for m in self.body:
-            _, max_index = torch.max(m.alpha, 0)
-            temp = torch.zeros(3, device=m.alpha.device)
-            temp[max_index] = 1
-            m.alpha.data = temp
-            m.alpha.requires_grad = flag
+        a = self.kind("alpha", self.flat.data)
+        a.copy_(F.one_hot(a.argmax(dim=1), 3).to(a.dtype))
+        self._set_frozen(("alpha",), not flag)
 
     @torch.no_grad()
     def get_mask_grad(self):

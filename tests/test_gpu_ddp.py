@@ -86,22 +86,24 @@ def test_ddp_two_ranks_full_batch_gradient_and_overlap(tmp_path):
 
 
 def test_nas_search_phases_rewrap_under_ddp(tmp_path):
-    """SURVEY 8 C5 hazard: the reference-shaped NAS_MODEL breaks stock DDP on the second iteration (beta / beta1 / beta2 never
-    receive gradients); models.wrap_ddp freezes exactly those and the three phases of search.py:290-405 (unwrap, toggle
-    length_grad / mask_grad, wrap again) then train with replicas staying bit-equal."""
+    """SURVEY 8 C5 hazard: the reference registers beta / beta1 / beta2 as Parameters that never receive gradients, which
+    breaks stock DDP on the second iteration.  NAS_MODEL keeps every block tensor as a slice of one flat parameter (zero
+    gradient there), so stock wrapping runs, and the three phases of search.py:290-405 (unwrap, toggle length_grad /
+    mask_grad, wrap again) train with the replicas staying bit-equal."""
     res = _run_two_ranks(tmp_path, "nas_phases")
-    assert res["stock_ddp_error"] and "finished reduction" in res["stock_ddp_error"], res["stock_ddp_error"]
+    assert res["stock_ddp_error"] is None, res["stock_ddp_error"]
     for ph in (1, 2, 3):
         assert res[f"phase{ph}_equal"], ph
     gate = lambda ks: [k for k in ks if k.endswith((".alpha1", ".alpha2"))]
     masks = lambda ks: [k for k in ks if k.endswith("split.weight") or k == "mask.weight"]
     convs = lambda ks: [k for k in ks if "weight_v" in k]
-    # phase 1: gates frozen, masks (requires_grad since construction) and kernels train
+    never = lambda ks: [k for k in ks if k.endswith(".beta")]
+    # phase 1: gates frozen, masks (trainable since construction) and kernels train
     assert not gate(res["phase1_changed"]) and masks(res["phase1_changed"]) and convs(res["phase1_changed"])
-    # phase 2: length_grad(True) turned beta1/beta2 back on (reference :573-577); wrap_ddp froze them again, and only them
-    assert res["phase2_frozen_now"] == [k for k in res["phase2_frozen_now"] if k.endswith(".beta")]
-    assert all(k.endswith((".beta", ".beta1", ".beta2")) for k in res["phase2_frozen_by_wrap"])
-    assert len(res["phase2_frozen_by_wrap"]) == 3 * 4
+    # phase 2: gates and masks train; nothing is frozen
+    assert res["phase2_frozen_kinds"] == []
     assert gate(res["phase2_changed"]) and masks(res["phase2_changed"])
     # phase 3: only kernels (and alpha) train
     assert not gate(res["phase3_changed"]) and not masks(res["phase3_changed"]) and convs(res["phase3_changed"])
+    for ph in (1, 2, 3):                                      # `beta` is never used and never moves (zero gradient, fresh Adam)
+        assert not never(res[f"phase{ph}_changed"])

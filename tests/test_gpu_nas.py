@@ -103,12 +103,12 @@ def test_nas_model_matches_oracle_glue(training):
     (torch.nn.functional.l1_loss(out, hr.cuda()) + 0.1 * speed.sum()).backward()
     (torch.nn.functional.l1_loss(ref, hr) + 0.1 * rspeed.sum()).backward()
     worst = 0.0
-    for k, p in m.named_parameters():
+    for k, pg in m.named_reference_tensors(grads=True):
         rg = sd[k].grad
         if rg is None or float(rg.abs().max()) == 0.0:
-            assert p.grad is None or float(p.grad.abs().max()) <= 1e-7, k
+            assert pg is None or float(pg.abs().max()) <= 1e-7, k
             continue
-        ge = (p.grad.cpu() - rg).abs().max().item() / rg.abs().max().item()
+        ge = (pg.cpu() - rg).abs().max().item() / rg.abs().max().item()
         worst = max(worst, ge)
         assert ge <= 5e-4, (k, ge)
     print(f"NAS model worst param-grad rel err {worst:.2e}")

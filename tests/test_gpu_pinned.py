@@ -46,17 +46,17 @@ def test_g10_nas_model_train_and_eval_match_reference(golden_dir):
     assert abs(l1.item() - d["loss_l1"].item()) <= 2e-6 and abs(ls.item() - d["loss_speed"].item()) <= 2e-6
     (l1 + ls).backward()
     worst, n = 0.0, 0
-    for k, p in m.named_parameters():
+    for k, pg in m.named_reference_tensors(grads=True):    # the reference's tensors, as views of the flat parameter's gradient
         if "speed_estimator" in k:
             continue
         if "g/" + k in d:
-            assert p.grad is not None, k
-            e = _rel(p.grad, d["g/" + k])
+            assert pg is not None, k
+            e = _rel(pg, d["g/" + k])
             worst = max(worst, e)
             assert e <= 5e-4, (k, e)
             n += 1
         else:                                                # beta, beta1, beta2: no gradient in the reference either
-            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            assert pg is None or float(pg.abs().max()) == 0.0, k
     assert n == 98
     print(f"\nG10 train: worst param-grad rel err {worst:.2e} over {n} tensors")
     for i in range(4):                                       # forward() rewrote the gates (wdsr_b.py:534)

@@ -64,9 +64,9 @@ def test_load_pretrained_is_positional_like_the_reference(tmp_path):
                             width_search=True, length_search=False, pretrained=False)
     torch.manual_seed(0)
     m = get_model(ns)
-    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    before = {k: v.detach().clone() for k, v in m.named_reference_tensors()}
     assert m.load_pretrained(path) == 3
-    for k, v in m.named_parameters():
+    for k, v in m.named_reference_tensors():
         if k in ("head.bias", "head.weight_g", "head.weight_v"):
             assert torch.equal(v, sd["head.0." + k.split(".")[1]])
         else:
@@ -83,18 +83,45 @@ def test_load_pretrained_is_positional_like_the_reference(tmp_path):
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "g10_nas_model.npz"))
     ref_order = [k[2:] for k in z.keys() if k.startswith("p/")]
     ns16 = argparse.Namespace(**{**vars(ns), "pretrained": False, "num_blocks": len({k.split(".")[1] for k in ref_order if k.startswith("body.")})})
-    mine = [k for k, _ in get_model(ns16).named_parameters() if not k.startswith("speed_estimator")]
-    assert mine == ref_order
+    mine = [k for k, _ in get_model(ns16).named_reference_tensors() if not k.startswith("speed_estimator")]
+    assert mine == ref_order                                 # the positional walk is over these, in this order
 
 
-def test_freeze_gradless_parameters_names():
+def test_flat_body_parameter_views_and_freezing():
+    """NAS_MODEL keeps the 25 tensors per block as views of ONE flat parameter: reference keys round-trip, body[i].x views
+    write through, and length_grad / mask_grad / kernel_grad freeze kinds by zeroing their gradient slices"""
     import argparse
+    import torch
     from mobilesuperresolution_amd.models import get_model
+    from mobilesuperresolution_amd.models.wdsr_b import _SplitFlat
     ns = argparse.Namespace(model_type="NAS_MODEL", image_mean=0.5, num_channels=3, scale=2, num_blocks=3, num_residual_units=24,
                             width_search=True, length_search=False, pretrained=False)
+    torch.manual_seed(1)
     m = get_model(ns)
+    names = [k for k, _ in m.named_parameters()]
+    assert names[0] == "flat" and not any(k.startswith("body.") for k in names)
+    assert m.gradless_parameters() == [] and m.freeze_gradless_parameters() == []
+    sd = m.state_dict()
+    assert sd["body.2.body.7.0.body.0.weight_v"].shape == (24, 1, 7, 7) and sd["body.1.alpha1"].shape == (1,)
+    with torch.no_grad():
+        m.body[1].alpha1.fill_(1.5)
+        m.body[2].split.weight.mul_(0.0)
+    assert float(m.state_dict()["body.1.alpha1"]) == 1.5 and float(m.state_dict()["body.2.split.weight"].abs().sum()) == 0.0
+    assert m.get_current_blocks() == 2 and m.get_block_status() == [0, 2]
+    m2 = get_model(ns)
+    m2.load_state_dict(m.state_dict())
+    assert torch.equal(m2.flat, m.flat)
+    # freezing: gradient slices of the frozen kinds are exactly zero, the others flow
+    m.length_grad(False)
+    m.mask_grad(False)
+    outs = _SplitFlat.apply(m.flat, m._layout, m._frozen)
+    sum((o.float() ** 2).sum() for o in outs if o.requires_grad).backward()
+    for kind in ("alpha1", "alpha2", "beta1", "beta2", "split.weight"):
+        assert float(m.kind(kind, m.flat.grad).abs().sum()) == 0.0, kind
+    assert float(m.kind("alpha", m.flat.grad).abs().sum()) > 0 and not m.mask.weight.requires_grad
     m.length_grad(True)
-    got = m.freeze_gradless_parameters()
-    assert got == [f"body.{i}.{n}" for i in range(3) for n in ("beta", "beta1", "beta2")]
-    assert m.freeze_gradless_parameters() == []
-    assert all(p.requires_grad for k, p in m.named_parameters() if k.endswith((".alpha1", ".alpha2", ".alpha")))
+    m.mask_grad(True)
+    assert m._frozen == frozenset() and m.mask.weight.requires_grad
+    m.kernel_grad(False)
+    a = m.kind("alpha")
+    assert torch.equal(a.sum(1), torch.ones(3)) and set(a.unique().tolist()) == {0.0, 1.0} and "alpha" in m._frozen
