@@ -195,11 +195,14 @@ class _NasBodyFunction(torch.autograd.Function):
         ys = torch.empty((nb + 1, n, h, w, f), dtype=dt, device=dev)
         ys[0] = y0
         V = torch.empty((nb, 3, n, h, w, f), dtype=dt, device=dev)
-        st, lib = L.stream_ptr, L.lib()
+        sp, lib = L.stream_ptr(), L.lib()                    # one stream lookup per call, not per launch
+        ysp, Vp, dwpp, frp, tbp, scp = (t.data_ptr() for t in (ys, V, dwp, frags, tabs, scal))
+        ysz, Vsz = ys[0].numel() * ys.element_size(), V[0].numel() * V.element_size()
+        dsz, fsz, tsz, ssz = (t.stride(0) * t.element_size() for t in (dwp, frags, tabs, scal))
         for i in range(nb):
-            L.launch("sr_nas_dw_fwd", lib.sr_nas_dw_fwd, ys[i].data_ptr(), V[i].data_ptr(), dwp[i].data_ptr(), n, h, w, f, code, st())
-            L.launch("sr_nas_pw_fwd", lib.sr_nas_pw_fwd, ys[i].data_ptr(), V[i].data_ptr(), ys[i + 1].data_ptr(),
-                     frags[i].data_ptr(), tabs[i].data_ptr(), scal[i].data_ptr(), n, h, w, f, code, st())
+            L.launch("sr_nas_dw_fwd", lib.sr_nas_dw_fwd, ysp + i * ysz, Vp + i * Vsz, dwpp + i * dsz, n, h, w, f, code, sp)
+            L.launch("sr_nas_pw_fwd", lib.sr_nas_pw_fwd, ysp + i * ysz, Vp + i * Vsz, ysp + (i + 1) * ysz,
+                     frp + i * fsz, tbp + i * tsz, scp + i * ssz, n, h, w, f, code, sp)
         ctx.save_for_backward(ys, V, dwp, frags, tabs, scal, MSf, P.detach().float(), BETA.detach().float())
         return ys[nb]
 
@@ -216,15 +219,18 @@ class _NasBodyFunction(torch.autograd.Function):
         part_dw = torch.empty((nb, wgs, tb["dw_slab"]), dtype=torch.float32, device=dev)
         g = gy.contiguous()
         gbuf = [torch.empty_like(g), torch.empty_like(g)]
-        st, lib = L.stream_ptr, L.lib()
+        sp, lib = L.stream_ptr(), L.lib()
+        ysp, Vp, dwpp, frp, tbp, scp, ppw, pdw, GZp = (t.data_ptr() for t in (ys, V, dwp, frags, tabs, scal, part_pw, part_dw, GZ))
+        ysz, Vsz = ys[0].numel() * ys.element_size(), V[0].numel() * V.element_size()
+        dsz, fsz, tsz, ssz, pwz, dwz = (t.stride(0) * t.element_size() for t in (dwp, frags, tabs, scal, part_pw, part_dw))
         for i in range(nb - 1, -1, -1):
             gin = gbuf[i & 1]
-            L.launch("sr_nas_pw_bwd", lib.sr_nas_pw_bwd, ys[i].data_ptr(), V[i].data_ptr(), g.data_ptr(), GZ.data_ptr(),
-                     frags[i].data_ptr(), tabs[i].data_ptr(), scal[i].data_ptr(), part_pw[i].data_ptr(), wgs, n, h, w, f, code, st())
-            L.launch("sr_nas_dw_bwd", lib.sr_nas_dw_bwd, ys[i].data_ptr(), GZ.data_ptr(), g.data_ptr(), gin.data_ptr(),
-                     dwp[i].data_ptr(), part_dw[i].data_ptr(), wgs, n, h, w, f, code, st())
-            L.launch("sr_nas_dw_wgrad", lib.sr_nas_dw_wgrad, ys[i].data_ptr(), GZ.data_ptr(), dwp[i].data_ptr(),
-                     part_dw[i].data_ptr(), wgs, n, h, w, f, code, st())
+            gp, ginp = g.data_ptr(), gin.data_ptr()
+            L.launch("sr_nas_pw_bwd", lib.sr_nas_pw_bwd, ysp + i * ysz, Vp + i * Vsz, gp, GZp, frp + i * fsz, tbp + i * tsz,
+                     scp + i * ssz, ppw + i * pwz, wgs, n, h, w, f, code, sp)
+            L.launch("sr_nas_dw_bwd", lib.sr_nas_dw_bwd, ysp + i * ysz, GZp, gp, ginp, dwpp + i * dsz, pdw + i * dwz, wgs, n, h, w, f,
+                     code, sp)
+            L.launch("sr_nas_dw_wgrad", lib.sr_nas_dw_wgrad, ysp + i * ysz, GZp, dwpp + i * dsz, pdw + i * dwz, wgs, n, h, w, f, code, sp)
             g = gin
         spw, sdw = part_pw.sum(1), part_dw.sum(1)                                      # (nb, slab)
         g_wpw = spw.index_select(1, tb["g_wpw"]).view(nb, 3, f, f, 1, 1)
