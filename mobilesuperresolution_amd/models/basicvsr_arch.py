@@ -206,7 +206,10 @@ class ConvResidualBlocks(nn.Module):
             raise L.HotpathError("ConvResidualBlocks (MI355X hot path) needs CUDA/HIP tensors; there is no CPU fallback")
         if fea.dim() != 4 or fea.shape[1] != self.num_in_ch:
             raise ValueError(f"expected N x {self.num_in_ch} x H x W input, got {tuple(fea.shape)}")
-        return _TrunkFunction.apply(fea, self, self.flat)
+        if fea.device != self.flat.device:
+            raise L.HotpathError(f"input on {fea.device}, parameters on {self.flat.device}")
+        with torch.cuda.device(fea.device):          # kernels go to THIS device's current stream
+            return _TrunkFunction.apply(fea, self, self.flat)
 
     def forward_warped(self, frame, state=None, flow=None, flow_bound=None):
         """through __call__, so that module hooks see the fused step too (their output is the (features, state) pair)"""
@@ -227,6 +230,9 @@ class ConvResidualBlocks(nn.Module):
             raise ValueError(f"expected N x 3 x H x W frames, got {tuple(frame.shape)}")
         if flow is not None and state is None:
             raise ValueError("a flow without a state to warp")
+        for name, t in (("frame", frame), ("state", state), ("flow", flow)):
+            if t is not None and t.device != self.flat.device:
+                raise L.HotpathError(f"{name} on {t.device}, parameters on {self.flat.device}")
         if flow is not None and flow_bound is None:
             flow_bound = flow.detach().abs().amax()
         return _TrunkWarpFunction.apply(frame, state, flow, flow_bound, self, self.flat)
@@ -264,6 +270,11 @@ class _TrunkFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        with torch.cuda.device(ctx.x0.device):
+            return _TrunkFunction._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         mod, x0, acts, mids, blob = ctx.mod, ctx.x0, ctx.acts, ctx.mids, ctx.blob
         dt, nb, cin = mod.hot_dtype, mod.num_block, mod.num_in_ch
         n, h, w, ci0 = x0.shape

@@ -98,3 +98,31 @@ def test_patch_oracle_shapes_and_flip_order():
     crop = lr[3:7, 5:9][::-1]
     assert np.array_equal(l, np.swapaxes(crop, 0, 1).transpose(2, 0, 1).astype(np.float32) / np.float32(255))
     assert h[0, 0, 0] == np.float32(hr[13, 10, 0]) / np.float32(255)                        # HR crop rows 6..13 flipped -> first is row 13
+
+
+def test_device_mismatch_is_a_python_error_not_a_gpu_fault():
+    """tensors on different devices must raise before any kernel is enqueued (checked with meta / cpu stand-ins:
+    the comparison happens before any device call)"""
+    import pytest
+    import torch
+    from mobilesuperresolution_amd import _lib as L
+    from mobilesuperresolution_amd.models import ConvResidualBlocks, flow_warp
+    t = ConvResidualBlocks(27, 24, 1)
+    with pytest.raises(L.HotpathError):
+        t(torch.zeros(1, 27, 8, 8))                           # CPU tensor: refused, no fallback
+    with pytest.raises(L.HotpathError):
+        flow_warp(torch.zeros(1, 4, 8, 8), torch.zeros(1, 8, 8, 2))
+
+    class FakeCuda(torch.Tensor):                             # claims to live on cuda:1 while the parameters are elsewhere
+        @property
+        def is_cuda(self):
+            return True
+
+        @property
+        def device(self):
+            return torch.device("cuda", 1)
+    x = torch.zeros(1, 27, 8, 8).as_subclass(FakeCuda)
+    with pytest.raises(L.HotpathError, match="parameters on"):
+        t(x)
+    with pytest.raises(L.HotpathError, match="parameters on"):
+        t.forward_warped(torch.zeros(1, 3, 8, 8).as_subclass(FakeCuda))
