@@ -4,6 +4,7 @@
 #include "../../include/sr_hotpath.h"
 #include "wdsr_block.h"
 #include "wdsr_fwd_rs.h"
+#include "wdsr_wgrad_rs.h"
 #include "wdsr_ends.h"
 #include "wdsr_prep.h"
 #include "conv3x3.h"
@@ -178,9 +179,17 @@ int launch_wgrad_saved(const void* x, const void* dy, const void* tsave, const v
   typedef __bf16 T;
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
   dim3 grid(wgs, layers);
-  hipLaunchKernelGGL((wdsr_block_wgrad_saved_kernel<T, F, E, L, 0>), grid, dim3(64 * WgradSavedCfg<F, E, L, 0>::NWAVES), 0, st,
-                     (const T*)x, (const T*)dtsave, (const T*)wblob, cinit, pa, N, H, W, tiles_x, tiles_x * tiles_y, x_ls,
-                     side_ls, w_ls, c_ls);
+  static const bool env_a15 = getenv("SR_WGRAD_A15") != nullptr;        // the 15-wave kernel, kept for A/B measurements
+  const bool old_a = env_a15 || (long)N * tiles_x * tiles_y * C::TH * C::TW >= (1L << 31);   // (the 8-wave kernel indexes pixels in 32 bits)
+  if constexpr (F == 24) {
+    if (!old_a)
+      hipLaunchKernelGGL((wdsr_wgrad_a8_kernel<F, E, L>), grid, dim3(WgradA8Cfg<F, E, L>::NTHREADS), 0, st, (const T*)x, (const T*)dtsave,
+                         (const T*)wblob, pa, N, H, W, tiles_x, tiles_x * tiles_y, x_ls, side_ls, w_ls);
+  }
+  if (F != 24 || old_a)
+    hipLaunchKernelGGL((wdsr_block_wgrad_saved_kernel<T, F, E, L, 0>), grid, dim3(64 * WgradSavedCfg<F, E, L, 0>::NWAVES), 0, st,
+                       (const T*)x, (const T*)dtsave, (const T*)wblob, cinit, pa, N, H, W, tiles_x, tiles_x * tiles_y, x_ls,
+                       side_ls, w_ls, c_ls);
   hipLaunchKernelGGL((wdsr_block_wgrad_saved_kernel<T, F, E, L, 1>), grid, dim3(64 * WgradSavedCfg<F, E, L, 1>::NWAVES), 0, st,
                      (const T*)dy, (const T*)tsave, (const T*)wblob, cinit, pb, N, H, W, tiles_x, tiles_x * tiles_y, dy_ls,
                      side_ls, w_ls, c_ls);
