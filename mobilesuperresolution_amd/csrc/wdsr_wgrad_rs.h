@@ -183,3 +183,136 @@ __global__ __launch_bounds__((WgradA8Cfg<F, E, L>::NTHREADS)) void wdsr_wgrad_a8
     }
   }
 }
+
+// =============================================================================================
+// Weight gradients of the 3x3 conv (dW3, and b3 through t's ones channel) from the saved t images, second design.
+// wdsr_block_wgrad_saved_kernel<ROLE 1> gives every tap its own wave: nine waves read the SAME transposed t fragments and
+// each MFMA fetches both of its operands from LDS (2 KB per MFMA; the kernel sat at 21 % MFMA busy).  Here a wave owns all
+// nine taps (144 accumulator registers) of one 4x8 pixel tile of the spatial tile: t's two fragments are read once for
+// 18 MFMAs, only dy's shifted fragments are per tap.  A 12x24 tile has nine pixel tiles for eight waves: the ninth is
+// split by TAP (every wave holds every tap's accumulator), one tap per wave and two for wave 0, so the waves stay level.
+// Both operands are staged by LDS-DMA, t as it lies, dy on its 1-pixel halo with 48-byte rows (conflict-free).
+// Slab layout: that of ROLE 1 ([tap][16 regs][64 lanes]).
+// =============================================================================================
+template <int F, int E, int L> struct WgradB8Cfg {
+  typedef BlockCfg<F, E, L> C;
+  typedef BwdCfg<C> B;
+  static constexpr int NWAVES = 8, NTHREADS = 64 * NWAVES;
+  static constexpr int IMG_ELEMS = (B::NPXC + 1) * 32;                 // t: [core px][32 ch]
+  static constexpr int PXP = 21;                                       // dy pixels per DMA piece (63 chunks + 1 of the next pixel)
+  static constexpr int NPD = (C::NPXH + PXP - 1) / PXP;                // dy pieces per tile
+  static constexpr int DY_ELEMS = (NPD * PXP + 1) * C::F + 32;         // dy halo tile, rows of F, + the last piece's spill
+  static constexpr int NPI = B::NPXC / 16;                             // t pieces per tile (16 px x 4 chunks)
+  static constexpr int BUF_ELEMS = IMG_ELEMS + DY_ELEMS;
+  static constexpr int LDS_BYTES = 2 * BUF_ELEMS * 2;
+  static_assert(C::FC == 3 && C::NPT_O == 9 && B::NPXC % 16 == 0, "24 units, 12x24 tiles");
+  static_assert(LDS_BYTES >= NWAVES * 2 * 4096, "the epilogue reduces two taps of every wave at a time in the staging buffers");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <int F, int E, int L>
+__global__ __launch_bounds__((WgradB8Cfg<F, E, L>::NTHREADS)) void wdsr_wgrad_b8_kernel(
+    const __bf16* __restrict__ dyact, const __bf16* __restrict__ side, float* __restrict__ partial, int N, int H, int W,
+    int tiles_x, int tiles_per_img, long act_ls, long side_ls) {
+  typedef __bf16 T;
+  typedef WgradB8Cfg<F, E, L> G;
+  typedef typename G::C C;
+  typedef typename G::B B;
+  __shared__ __attribute__((aligned(16))) char smem_raw[G::LDS_BYTES];
+  T* const BUF = reinterpret_cast<T*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int layer = blockIdx.y;
+  dyact += (size_t)layer * act_ls;
+  side += (size_t)layer * side_ls;
+  const int total = N * tiles_per_img;
+  const char* zeros = reinterpret_cast<const char*>(g_sr_const_chunks) + 16;
+
+  auto stage = [&](int t, int buf) {
+    T* IMGb = BUF + buf * G::BUF_ELEMS;
+    T* DYb = IMGb + G::IMG_ELEMS;
+    const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
+    const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+    const T* sp = side + (size_t)t * (B::NPXC * C::LP);
+    const T* dimg = dyact + (size_t)n * H * W * F;
+#pragma unroll 1
+    for (int p = wave; p < G::NPI + G::NPD; p += G::NWAVES) {
+      if (p < G::NPI) {                              // t: 16 pixels x (3 chunks + a zero chunk) per piece, rows of 32 channels
+        const int c = lane & 3, px = p * 16 + (lane >> 2);
+        const char* src = c < C::CPT ? reinterpret_cast<const char*>(sp + (size_t)px * C::LP + c * 8) : zeros;
+        dma_piece16(src, lds_addr(IMGb) + p * 1024);
+      } else {                                       // dy on the 1-pixel halo: 21 pixels x 3 chunks (+ 1 chunk the next piece rewrites)
+        const int q = p - G::NPI, lq = lane / 3, lc = lane - lq * 3;
+        const int hp = q * G::PXP + lq;
+        const int hy = hp / C::HW, hx = hp - hy * C::HW;
+        const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
+        const char* src = zeros;
+        if (hp < C::NPXH && Y >= 0 && Y < H && X >= 0 && X < W)
+          src = reinterpret_cast<const char*>(dimg + ((size_t)Y * W + X) * F + lc * 8);
+        dma_piece16(src, lds_addr(DYb) + q * (G::PXP * C::F * 2));
+      }
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int u = 0; u < 9; ++u) acc[u] = zero16();
+
+  int cur = 0;
+  if ((int)blockIdx.x < total) stage(blockIdx.x, 0);
+  for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    wait_vmcnt<0>();
+    __syncthreads();
+    if (t + (int)gridDim.x < total) stage(t + gridDim.x, cur ^ 1);
+    const T* IMG = BUF + cur * G::BUF_ELEMS;
+    const T* DYs = IMG + G::IMG_ELEMS;
+    {                                                // this wave's own pixel tile: all nine taps
+      const int ot = wave;
+      const int toy = (ot / (C::TW / 8)) * 4, tox = (ot % (C::TW / 8)) * 8;
+      auto rowi = [=](int p) { return ((toy + (p >> 3)) * C::TW + tox + (p & 7)) * 32; };
+      const bf16x8 a0 = tr_frag<T>(IMG, 0, lane, rowi), a1 = tr_frag<T>(IMG, 1, lane, rowi);
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        const int uy = u / 3, ux = u - uy * 3;
+        auto rowd = [=](int p) { return ((toy + (p >> 3) + uy) * C::HW + tox + (p & 7) + ux) * C::F; };
+        acc[u] = mma16<T>(a0, tr_frag<T>(DYs, 0, lane, rowd), acc[u]);
+        acc[u] = mma16<T>(a1, tr_frag<T>(DYs, 1, lane, rowd), acc[u]);
+      }
+    }
+    {                                                // the ninth pixel tile, split by tap: tap = wave (and tap 8 for wave 0)
+      constexpr int ot = 8;
+      constexpr int toy = (ot / (C::TW / 8)) * 4, tox = (ot % (C::TW / 8)) * 8;
+      auto rowi = [=](int p) { return ((toy + (p >> 3)) * C::TW + tox + (p & 7)) * 32; };
+      const bf16x8 a0 = tr_frag<T>(IMG, 0, lane, rowi), a1 = tr_frag<T>(IMG, 1, lane, rowi);
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        if (u == wave || (u == 8 && wave == 0)) {    // wave-uniform
+          const int uy = u / 3, ux = u - uy * 3;
+          auto rowd = [=](int p) { return ((toy + (p >> 3) + uy) * C::HW + tox + (p & 7) + ux) * C::F; };
+          acc[u] = mma16<T>(a0, tr_frag<T>(DYs, 0, lane, rowd), acc[u]);
+          acc[u] = mma16<T>(a1, tr_frag<T>(DYs, 1, lane, rowd), acc[u]);
+        }
+      }
+    }
+    cur ^= 1;
+  }
+
+  // ---- reduce the eight waves' accumulators, two taps at a time, through the staging buffers ----
+  float* out = partial + ((size_t)layer * gridDim.x + blockIdx.x) * B::SLAB_B;
+  float* red = reinterpret_cast<float*>(smem_raw);   // [wave][2 taps][16 regs][64 lanes]
+  wait_vmcnt<0>();
+#pragma unroll
+  for (int u0 = 0; u0 < 9; u0 += 2) {
+    __syncthreads();
+    slab_store_tile(red + wave * 2048, 0, acc[u0], lane);
+    if (u0 + 1 < 9) slab_store_tile(red + wave * 2048, 1, acc[u0 + 1 < 9 ? u0 + 1 : 8], lane);
+    __syncthreads();
+    const int nval = u0 + 1 < 9 ? 2048 : 1024;
+    for (int i = tid; i < nval; i += G::NTHREADS) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < G::NWAVES; ++w) v += red[w * 2048 + i];
+      out[u0 * 1024 + i] = v;
+    }
+  }
+}
