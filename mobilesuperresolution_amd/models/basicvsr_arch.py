@@ -238,6 +238,14 @@ class ConvResidualBlocks(nn.Module):
         return _TrunkWarpFunction.apply(frame, state, flow, flow_bound, self, self.flat)
 
 
+def _wgrad_wgs(n, h, w, cap=72):
+    """workgroups per conv for the weight-gradient launches: every workgroup walks the same number of 12x24 tiles (144 tiles
+    at C4 -> 72 workgroups x 2 tiles; 64 workgroups left a quarter of them idle in the third round)"""
+    total = n * ((h + 11) // 12) * ((w + 23) // 24)
+    per = -(-total // cap)
+    return -(-total // per)
+
+
 def _launch(name, *args):
     L.launch(name, getattr(L.lib(), name), *args, L.stream_ptr())
 
@@ -279,7 +287,7 @@ class _TrunkFunction(torch.autograd.Function):
         dt, nb, cin = mod.hot_dtype, mod.num_block, mod.num_in_ch
         n, h, w, ci0 = x0.shape
         dev = x0.device
-        wgs = 64
+        wgs = _wgrad_wgs(n, h, w)
         _, grad_idx, boff, _ = _trunk_tables(mod.cin_k, nb, dev.index if dev.index is not None else torch.cuda.current_device())
         ga = torch.empty_like(acts)                                                  # gradient at a_0 .. a_nb
         gt = torch.empty_like(mids)
@@ -359,7 +367,7 @@ class _TrunkWarpFunction(torch.autograd.Function):
         _, n, h, w, _ = acts.shape
         dev = acts.device
         need_frame, need_state, need_flow = ctx.need
-        wgs = 64
+        wgs = _wgrad_wgs(n, h, w)
         with torch.cuda.device(dev):
             _, _, boff, _ = _trunk_tables(27, nb, dev.index)
             s0, d0, s1, d1 = _unpack_tables(27, dev.index)
