@@ -69,6 +69,24 @@ static int launch_fwd_rs(const void* x, void* ya, void* yb, const void* wa, cons
   typedef BlockCfg<F, E, L> C;
   typedef __bf16 T;
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
+  static const int persist_from = getenv("SR_RS_PERSIST_FROM") ? atoi(getenv("SR_RS_PERSIST_FROM")) : 1024;
+  const long total = (long)N * tiles_x * tiles_y;
+  if (total >= persist_from && total < (1L << 31)) {   // many tiles per CU: the persistent form (one workgroup per CU)
+    const int wgs = 256;
+    const bool save = tsa && (NBLK == 1 || tsb);
+    if (save && NBLK == 1) {
+      hipLaunchKernelGGL((wdsr_fwd_rs_persist_kernel<F, E, L, 1, true>), dim3(wgs), dim3(512), 0, st, (const T*)x, (T*)ya, (T*)yb,
+                         (const T*)wa, (const T*)wb, cia, cib, (T*)tsa, (T*)tsb, N, H, W, tiles_x, tiles_x * tiles_y);
+      SR_HIP_CHECK_LAUNCH();
+      return 0;
+    }
+    if (!save) {
+      hipLaunchKernelGGL((wdsr_fwd_rs_persist_kernel<F, E, L, NBLK, false>), dim3(wgs), dim3(512), 0, st, (const T*)x, (T*)ya, (T*)yb,
+                         (const T*)wa, (const T*)wb, cia, cib, (T*)tsa, (T*)tsb, N, H, W, tiles_x, tiles_x * tiles_y);
+      SR_HIP_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   if (tsa && (NBLK == 1 || tsb))
     hipLaunchKernelGGL((wdsr_fwd_rs_kernel<F, E, L, NBLK, true>), dim3(tiles_x * tiles_y, N), dim3(512), 0, st, (const T*)x, (T*)ya,
                        (T*)yb, (const T*)wa, (const T*)wb, cia, cib, (T*)tsa, (T*)tsb, H, W, tiles_x);
@@ -692,11 +710,11 @@ static bool net_saves_side_images(const sr_wdsr_net_t* n, bool backward) {
 // Two blocks per launch pay while a launch is bound by its fixed costs (about one workgroup per CU); with more
 // workgroups the single-block kernels win (two resident per CU, no halo-2 recompute): measured crossover at
 // batch 64 of 48x48 patches = 512 workgroups (tools/bench_rows.py).
-static bool net_uses_pairs(const sr_wdsr_net_t* n) {
+static long net_tiles(const sr_wdsr_net_t* n) {
   typedef BlockCfg<24, 144, 20> C;
-  const long wgs = (long)n->N * ((n->W + C::TW - 1) / C::TW) * ((n->H + C::TH - 1) / C::TH);
-  return n->F == 24 && n->dtype == SR_DTYPE_BF16 && wgs <= 384;
+  return (long)n->N * ((n->W + C::TW - 1) / C::TW) * ((n->H + C::TH - 1) / C::TH);
 }
+static bool net_uses_pairs(const sr_wdsr_net_t* n) { return n->F == 24 && n->dtype == SR_DTYPE_BF16 && net_tiles(n) <= 384; }
 static size_t side_image_bytes(const sr_wdsr_net_t* n) {     // one block's [N][tiles][288][LP] image
   typedef BlockCfg<24, 144, 20> C;
   const size_t tiles = (size_t)((n->W + C::TW - 1) / C::TW) * ((n->H + C::TH - 1) / C::TH);
@@ -718,7 +736,9 @@ extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int flags, sr_stream_
   char* acts = (char*)n->acts;
   if ((rc = sr_head_fwd(n->x, acts, n->blob_head, n->mean, n->N, n->H, n->W, n->F, n->dtype, stream))) return rc;
   char* cur = acts;
-  const bool pairs = net_uses_pairs(n);
+  // inference over many tiles per CU: the persistent two-block launches (csrc/wdsr_fwd_rs.h) beat the single-block ones
+  // again (0.29 vs 0.27 of the roof at batch 512); with saved images (training) the large grids stay on single blocks
+  const bool pairs = net_uses_pairs(n) || (!save_acts && n->F == 24 && n->dtype == SR_DTYPE_BF16 && net_tiles(n) >= 1024);
   const bool saved = net_saves_side_images(n, false);
   const size_t side = side_image_bytes(n);
   for (int i = 0; i < n->NB; ++i) {

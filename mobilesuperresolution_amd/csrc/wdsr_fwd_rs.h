@@ -521,3 +521,127 @@ __global__ __launch_bounds__(512) void wdsr_fwd_rs_kernel(const __bf16* __restri
   }
   SR_STAMP();
 }
+
+// =============================================================================================
+// PERSISTENT form for grids of many tiles per CU (batch >> 32): one workgroup per CU walks the tiles
+// t = blockIdx.x, += gridDim.x.  Both blocks' weights and the C-init tables are staged ONCE per workgroup and stay in
+// LDS; the next tile's x region lands by LDS-DMA in a second buffer while the current tile computes; block 0's conv1 /
+// conv2 weights for the next tile are prefetched LDS -> registers under the current tile's last phase.  What a tile pays
+// is its four phases and five barriers: no dispatch ramp, no staging in front of the first MFMA.  (The two-block variant
+// that also saves the t images does not fit 256 registers with the loop-carried state: training at such batch sizes keeps
+// the per-tile launches.)  Same phases, same
+// results as wdsr_fwd_rs_kernel (bit-identical).
+// =============================================================================================
+template <int F, int E, int L, int NBLK, bool SAVE_T>
+__global__ __launch_bounds__(512) void wdsr_fwd_rs_persist_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ ya,
+                                                                  __bf16* __restrict__ yb, const __bf16* __restrict__ wa,
+                                                                  const __bf16* __restrict__ wb, const float* __restrict__ cia,
+                                                                  const float* __restrict__ cib, __bf16* __restrict__ tsa,
+                                                                  __bf16* __restrict__ tsb, int N, int H, int W, int tiles_x,
+                                                                  int tiles_per_img) {
+  typedef BlockCfg<F, E, L> C;
+  typedef RsCfg<F, E, L, NBLK> R;
+  constexpr int NW = R::NWAVES;
+  // The last DMA piece of an x region runs up to 1 KB past it.  In the per-tile kernel that lands in the not-yet-written t
+  // image; here the NEXT tile's x arrives while the current tile's t image is in use, so both x buffers carry their own slack.
+  constexpr int X0S_ELEMS = R::X0_ELEMS + 512;
+  static_assert(R::LDS_BYTES + (X0S_ELEMS + 512) * 2 <= 160 * 1024, "LDS budget with the second x buffer");
+  __shared__ __attribute__((aligned(16))) char smem_raw[R::LDS_BYTES + (X0S_ELEMS + 512) * 2];
+  __bf16* const X0a = reinterpret_cast<__bf16*>(smem_raw);
+  __bf16* const TT = X0a + X0S_ELEMS;
+  __bf16* const X1 = TT + R::TT_ELEMS;
+  __bf16* const WL = X1 + R::X1_ELEMS;
+  __bf16* const ONES = WL + NBLK * R::W_ELEMS;
+  float* const CL = reinterpret_cast<float*>(ONES + R::ONES_ELEMS);
+  __bf16* const X0b = reinterpret_cast<__bf16*>(smem_raw + R::LDS_BYTES + 1024);
+  constexpr int KXL = R::KXL;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int total = N * tiles_per_img;
+  const char* zeros = reinterpret_cast<const char*>(g_sr_const_chunks) + 16;
+
+  auto stage_x = [&](int t, __bf16* X0) {              // the halo'd x region of tile t: 21 pixels x 3 chunks (+ 1 chunk) per piece
+    const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
+    const int y0 = (tile / tiles_x) * C::TH - NBLK, x0 = (tile % tiles_x) * C::TW - NBLK;
+    const size_t img = (size_t)n * H * W * F;
+    const int lq = lane / C::FC, lc = lane - lq * C::FC;
+#pragma unroll 1
+    for (int p = wave; p < R::NPX; p += NW) {
+      const int px_ = p * R::PXP + lq;
+      const int py = px_ / R::rw(0), pxx = px_ - py * R::rw(0);
+      const int Y = y0 + py, X = x0 + pxx;
+      const char* src = zeros;
+      if (px_ < R::np(0) && Y >= 0 && Y < H && X >= 0 && X < W)
+        src = reinterpret_cast<const char*>(x + img + ((size_t)Y * W + X) * C::F + lc * 8);
+      dma_piece16(src, lds_addr(X0) + p * (R::PXP * C::FC * 16));
+    }
+  };
+  auto stage_const = [&]() {                           // C-init tables and every block's weights, once
+#pragma unroll 1
+    for (int p = R::P_C + wave; p < R::P_END; p += NW) {
+      if (p < R::P_W) {
+        const int k = p - R::P_C, blk = k / (R::CL_FLOATS / 64), i = (k % (R::CL_FLOATS / 64)) * 64 + lane;
+        const float* tab = (NBLK > 1 && blk == 1) ? cib : cia;
+        const char* src = i < C::CINIT_FWD ? reinterpret_cast<const char*>(tab + i) : zeros + (lane & 3) * 4;
+        dma_piece4(src, lds_addr(CL) + k * 256);
+      } else {
+        const int fr = p - R::P_W;
+        const __bf16* wsrc = (NBLK > 1 && fr >= C::NFRAG_FWD) ? wb + (size_t)(fr - C::NFRAG_FWD) * 512 : wa + (size_t)fr * 512;
+        dma_piece16(reinterpret_cast<const char*>(wsrc + lane * 8), lds_addr(WL) + fr * 1024);
+      }
+    }
+  };
+
+  if ((int)blockIdx.x < total) stage_x(blockIdx.x, X0a);
+  stage_const();
+  if (tid < 8) ONES[tid] = tid == 0 ? (__bf16)1.f : (__bf16)0.f;
+  RwA<C> rwa;
+  RwB<C> rwb;
+  auto pf_a = [&](const __bf16* wl, int lo, int hi) {
+#pragma unroll
+    for (int i = 0; i < RwA<C>::N; ++i)
+      if (i >= lo && i < hi) rwa.load_one(wl, lane, i);
+  };
+  auto pf_b = [&](const __bf16* wl, int lo, int hi) {
+#pragma unroll
+    for (int i = 0; i < RwB<C>::N; ++i)
+      if (i >= lo && i < hi) rwb.load_one(wl, lane, i);
+  };
+  bool first = true;
+  int cur = 0;
+  for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    __bf16* const X0 = cur ? X0b : X0a;
+    const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
+    const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+    const size_t img = (size_t)n * H * W * F;
+    wait_vmcnt<0>();                                   // this tile's x (and, the first time, the constants) landed
+    __syncthreads();                                   // ... for every wave; the previous tile's last phase is over
+    if (t + (int)gridDim.x < total) stage_x(t + gridDim.x, cur ? X0a : X0b);
+    if (first) {
+      rwa.load(WL, lane);
+      first = false;
+    }
+    __bf16* const tsa_tile = SAVE_T ? tsa + (size_t)t * (C::TH * C::TW) * C::LP : nullptr;
+    __bf16* const tsb_tile = (SAVE_T && NBLK > 1) ? tsb + (size_t)t * (C::TH * C::TW) * C::LP : nullptr;
+    const bool more = t + (int)gridDim.x < total;
+    // ---- block 0 ----
+    rw_phase_a<C, KXL, R::rw(0), R::np(0), NBLK, NW, SAVE_T>(X0, ONES, TT, rwa, CL, tsa_tile, H, W, ty0, tx0, wave, lane,
+                                                               [&](int lo, int hi) { pf_b(WL, lo, hi); }, [] {});
+    __syncthreads();
+    if constexpr (NBLK == 1) {
+      rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NW>(TT, X0, nullptr, yb + img, rwb, H, W, ty0, tx0, wave, lane,
+                                                      [&](int lo, int hi) { if (more) pf_a(WL, lo, hi); });
+    } else {
+      rw_phase_b<C, KXL, R::rw(1), R::np(1), NBLK - 1, NW>(TT, X0, X1, ya ? ya + img : nullptr, rwb, H, W, ty0, tx0, wave, lane,
+                                                           [&](int lo, int hi) { pf_a(WL + R::W_ELEMS, lo, hi); });
+      __syncthreads();
+      // ---- block 1 ----
+      rw_phase_a<C, KXL, R::rw(1), R::np(1), NBLK - 1, NW, SAVE_T>(X1, ONES, TT, rwa, CL + R::CL_FLOATS, tsb_tile, H, W, ty0, tx0, wave,
+                                                                   lane, [&](int lo, int hi) { pf_b(WL + R::W_ELEMS, lo, hi); }, [] {});
+      __syncthreads();
+      rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NW>(TT, X1, nullptr, yb + img, rwb, H, W, ty0, tx0, wave, lane,
+                                                      [&](int lo, int hi) { if (more) pf_a(WL, lo, hi); });
+    }
+    cur ^= 1;
+  }
+}

@@ -288,3 +288,43 @@ def test_fused_tail_backward_bit_identical_to_two_launches(f, r, shape):
     # what the network consumes, slab by slab
     used = tb["tail_grad"]
     assert torch.equal(d_new, d_ref) and torch.equal(p_new.index_select(1, used), p_ref.index_select(1, used))
+
+
+@pytest.mark.parametrize("shape", [(150, 48, 48), (80, 50, 70)])
+def test_persistent_forward_for_many_tiles_bit_identical(shape):
+    """>= 1024 tiles per launch: sr_wdsr_fwd_rs takes its persistent form (one workgroup per CU walking the tiles, weights
+    staged once, the next tile's x landing under the current tile) -- same bits as the single-block kernels, for one block
+    with and without saved t images and for two blocks per launch; tile counts that do not divide by the workgroup count"""
+    from mobilesuperresolution_amd import _lib as L, hotpath as HP
+    n, h, w = shape
+    tiles = ((h + 11) // 12) * ((w + 23) // 24)
+    assert n * tiles >= 1024 and (n * tiles) % 256 != 0
+    f = 24
+    g = torch.Generator().manual_seed(29)
+    src = (torch.randn(2, HP.tables(f, torch.device("cuda", 0))["src_size"], generator=g) * 0.08).cuda()
+    src[:, -2], src[:, -1] = 0.0, 1.0
+    blob, cinit = HP.pack_blocks(src, f, torch.bfloat16)
+    x = torch.randn(n, h, w, f, generator=g).cuda().bfloat16()
+    lib = L.lib()
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    HP.block_fwd(x, y1, blob[0], cinit[0])
+    HP.block_fwd(y1, y2, blob[1], cinit[1])
+    # two blocks per launch, no saved images (inference)
+    p1, p2 = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+    L.check(lib.sr_wdsr_fwd_rs(x.data_ptr(), p1.data_ptr(), p2.data_ptr(), blob[0].data_ptr(), blob[1].data_ptr(), cinit[0].data_ptr(),
+                               cinit[1].data_ptr(), None, None, 2, n, h, w, f, 1, L.stream_ptr()), "rs2 persistent")
+    torch.cuda.synchronize()
+    assert torch.equal(p1, y1) and torch.equal(p2, y2)
+    # one block per launch with the saved t image, against the per-tile launches of a smaller batch (same per-tile layout)
+    ts = torch.full((n, tiles, 288, 24), float("nan"), device="cuda", dtype=torch.bfloat16)
+    q1 = torch.full_like(x, float("nan"))
+    L.check(lib.sr_wdsr_fwd_rs(x.data_ptr(), None, q1.data_ptr(), blob[0].data_ptr(), None, cinit[0].data_ptr(), None, ts.data_ptr(), None,
+                               1, n, h, w, f, 1, L.stream_ptr()), "rs1 persistent")
+    m = 5                                                 # 5 images: far below the persistent threshold
+    ts_small = torch.full((m, tiles, 288, 24), float("nan"), device="cuda", dtype=torch.bfloat16)
+    q_small = torch.empty_like(x[:m])
+    L.check(lib.sr_wdsr_fwd_rs(x[:m].contiguous().data_ptr(), None, q_small.data_ptr(), blob[0].data_ptr(), None, cinit[0].data_ptr(), None,
+                               ts_small.data_ptr(), None, 1, m, h, w, f, 1, L.stream_ptr()), "rs1 per tile")
+    torch.cuda.synchronize()
+    assert torch.equal(q1, y1) and torch.equal(q_small, y1[:m])
+    assert torch.equal(torch.nan_to_num(ts[:m], nan=-7.0), torch.nan_to_num(ts_small, nan=-7.0))
