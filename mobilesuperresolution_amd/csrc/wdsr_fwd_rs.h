@@ -645,3 +645,146 @@ __global__ __launch_bounds__(512) void wdsr_fwd_rs_persist_kernel(const __bf16* 
     cur ^= 1;
   }
 }
+
+// =============================================================================================
+// TWO-ROLE PIPELINE for grids of many tiles per CU (two blocks per launch, inference): the persistent loop above still
+// reloads a phase's weights LDS -> registers four times per tile (156 + 123 KB of LDS reads per block) and leaves half of
+// its MFMA slots to 32-pixel-tile rounding.  Here waves 0..3 ("A") keep conv1 / conv2 of BOTH blocks in registers (152
+// VGPRs), waves 4..7 ("B") both 3x3 convs (120): nothing is ever reloaded, and every SIMD hosts one wave of each role, so
+// that A's convert / ReLU work sits under B's MFMAs and the other way round.  The four phases of consecutive tiles are
+// skewed so that both roles always have work: round j is
+//     step 1:  A0(tile j)      ||  B1(tile j - 2)        barrier
+//     step 2:  A1(tile j - 1)  ||  B0(tile j)            barrier
+// (A0(j) -> B0(j) -> A1(j) -> B1(j) stay in order across the steps.)  LDS: x double-buffered (the next tile lands by
+// LDS-DMA), t of block 0, block 0's output double-buffered (A1 reads tile j - 1 while B0 writes tile j), t of block 1.
+// Same phase code, same results as wdsr_fwd_rs_kernel (bit-identical).
+// =============================================================================================
+template <int F, int E, int L>
+__global__ __launch_bounds__(512) void wdsr_fwd_rs_pipe_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ ya,
+                                                               __bf16* __restrict__ yb, const __bf16* __restrict__ wa,
+                                                               const __bf16* __restrict__ wb, const float* __restrict__ cia,
+                                                               const float* __restrict__ cib, int N, int H, int W, int tiles_x,
+                                                               int tiles_per_img) {
+  typedef BlockCfg<F, E, L> C;
+  typedef RsCfg<F, E, L, 2> R;
+  constexpr int NR = 4;                                                // waves per role
+  constexpr int X0S = R::X0_ELEMS + 512;                               // x region + its DMA slack
+  constexpr int TT0_ELEMS = R::npad(0) * C::LP, TT1_ELEMS = R::npad(1) * C::LP, X1_ELEMS = R::npad(1) * R::KXL;
+  constexpr int BUF_ELEMS = 2 * X0S + TT0_ELEMS + 2 * X1_ELEMS + TT1_ELEMS;
+  constexpr int LDS_BYTES = (BUF_ELEMS + R::ONES_ELEMS) * 2 + 2 * R::CL_FLOATS * 4;
+  static_assert((TT0_ELEMS + 2 * X1_ELEMS + TT1_ELEMS) >= 2 * R::W_ELEMS, "the weights are parked behind the x buffers until they are in registers");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES];
+  __bf16* const X0 = reinterpret_cast<__bf16*>(smem_raw);              // [2][X0S]
+  __bf16* const TT0 = X0 + 2 * X0S;
+  __bf16* const X1 = TT0 + TT0_ELEMS;                                  // [2][X1_ELEMS]
+  __bf16* const TT1 = X1 + 2 * X1_ELEMS;
+  __bf16* const ONES = TT1 + TT1_ELEMS;
+  float* const CL = reinterpret_cast<float*>(ONES + R::ONES_ELEMS);
+  __bf16* const WL = TT0;                                              // prologue only
+  constexpr int KXL = R::KXL;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int total = N * tiles_per_img;
+  const int K = ((int)blockIdx.x < total) ? (total - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;   // this workgroup's tiles
+  const char* zeros = reinterpret_cast<const char*>(g_sr_const_chunks) + 16;
+
+  auto tile_of = [&](int k, int& ty0, int& tx0, size_t& img) {
+    const int t = blockIdx.x + k * gridDim.x;
+    const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
+    ty0 = (tile / tiles_x) * C::TH;
+    tx0 = (tile % tiles_x) * C::TW;
+    img = (size_t)n * H * W * F;
+  };
+  auto stage_x = [&](int k, __bf16* dst) {             // the halo'd x region of this workgroup's k-th tile (all 8 waves)
+    int ty0, tx0;
+    size_t img;
+    tile_of(k, ty0, tx0, img);
+    const int y0 = ty0 - 2, x0 = tx0 - 2;
+    const int lq = lane / C::FC, lc = lane - lq * C::FC;
+#pragma unroll 1
+    for (int p = wave; p < R::NPX; p += R::NWAVES) {
+      const int px_ = p * R::PXP + lq;
+      const int py = px_ / R::rw(0), pxx = px_ - py * R::rw(0);
+      const int Y = y0 + py, X = x0 + pxx;
+      const char* src = zeros;
+      if (px_ < R::np(0) && Y >= 0 && Y < H && X >= 0 && X < W)
+        src = reinterpret_cast<const char*>(x + img + ((size_t)Y * W + X) * C::F + lc * 8);
+      dma_piece16(src, lds_addr(dst) + p * (R::PXP * C::FC * 16));
+    }
+  };
+
+  // ---- prologue: first x region, C-init tables, both blocks' weights (parked in the t / y buffers); weights -> registers ----
+  if (K > 0) stage_x(0, X0);
+#pragma unroll 1
+  for (int p = R::P_C + wave; p < R::P_END; p += R::NWAVES) {
+    if (p < R::P_W) {
+      const int k = p - R::P_C, blk = k / (R::CL_FLOATS / 64), i = (k % (R::CL_FLOATS / 64)) * 64 + lane;
+      const float* tab = blk == 1 ? cib : cia;
+      const char* src = i < C::CINIT_FWD ? reinterpret_cast<const char*>(tab + i) : zeros + (lane & 3) * 4;
+      dma_piece4(src, lds_addr(CL) + k * 256);
+    } else {
+      const int fr = p - R::P_W;
+      const __bf16* wsrc = fr >= C::NFRAG_FWD ? wb + (size_t)(fr - C::NFRAG_FWD) * 512 : wa + (size_t)fr * 512;
+      dma_piece16(reinterpret_cast<const char*>(wsrc + lane * 8), lds_addr(WL) + fr * 1024);
+    }
+  }
+  if (tid < 8) ONES[tid] = tid == 0 ? (__bf16)1.f : (__bf16)0.f;
+  wait_vmcnt<0>();
+  __syncthreads();
+
+  if (wave < NR) {
+    // ================= role A: conv1 -> ReLU -> conv2 of both blocks =================
+    RwA<C> w0, w1;
+    w0.load(WL, lane);
+    w1.load(WL + R::W_ELEMS, lane);
+    __syncthreads();                                   // every wave holds its weights: the parking area is free
+    for (int j = 0; j < K + 2; ++j) {
+      if (j + 1 < K) stage_x(j + 1, X0 + ((j + 1) & 1) * X0S);
+      if (j < K) {                                     // step 1: A0(j)
+        int ty0, tx0;
+        size_t img;
+        tile_of(j, ty0, tx0, img);
+        rw_phase_a<C, KXL, R::rw(0), R::np(0), 2, NR, false>(X0 + (j & 1) * X0S, ONES, TT0, w0, CL, nullptr, H, W, ty0, tx0, wave, lane,
+                                                             [](int, int) {}, [] {});
+      }
+      __syncthreads();
+      if (j >= 1 && j - 1 < K) {                       // step 2: A1(j - 1)
+        int ty0, tx0;
+        size_t img;
+        tile_of(j - 1, ty0, tx0, img);
+        rw_phase_a<C, KXL, R::rw(1), R::np(1), 1, NR, false>(X1 + ((j - 1) & 1) * X1_ELEMS, ONES, TT1, w1, CL + R::CL_FLOATS, nullptr, H, W,
+                                                             ty0, tx0, wave, lane, [](int, int) {}, [] {});
+      }
+      wait_vmcnt<0>();                                 // the next tile's x pieces this wave issued
+      __syncthreads();
+    }
+  } else {
+    // ================= role B: the 3x3 convs (+ residual) of both blocks =================
+    const int bw = wave - NR;
+    RwB<C> w0, w1;
+    w0.load(WL, lane);
+    w1.load(WL + R::W_ELEMS, lane);
+    __syncthreads();
+    for (int j = 0; j < K + 2; ++j) {
+      if (j + 1 < K) stage_x(j + 1, X0 + ((j + 1) & 1) * X0S);
+      if (j >= 2 && j - 2 < K) {                       // step 1: B1(j - 2)
+        int ty0, tx0;
+        size_t img;
+        tile_of(j - 2, ty0, tx0, img);
+        rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NR>(TT1, X1 + ((j - 2) & 1) * X1_ELEMS, nullptr, yb + img, w1, H, W, ty0, tx0, bw, lane,
+                                                        [](int, int) {});
+      }
+      __syncthreads();
+      if (j < K) {                                     // step 2: B0(j)
+        int ty0, tx0;
+        size_t img;
+        tile_of(j, ty0, tx0, img);
+        rw_phase_b<C, KXL, R::rw(1), R::np(1), 1, NR>(TT0, X0 + (j & 1) * X0S, X1 + (j & 1) * X1_ELEMS, ya ? ya + img : nullptr, w0, H, W,
+                                                      ty0, tx0, bw, lane, [](int, int) {});
+      }
+      wait_vmcnt<0>();
+      __syncthreads();
+    }
+  }
+}
