@@ -218,12 +218,10 @@ int launch_wgrad_saved(const void* x, const void* dy, const void* tsave, const v
                        (const T*)x, (const T*)dtsave, (const T*)wblob, cinit, pa, N, H, W, tiles_x, tiles_x * tiles_y, x_ls,
                        side_ls, w_ls, c_ls);
   static const bool old_b = getenv("SR_WGRAD_B9") != nullptr;           // the tap-per-wave kernel, kept for A/B measurements
-  if constexpr (F == 24) {
-    if (!old_b)
-      hipLaunchKernelGGL((wdsr_wgrad_b8_kernel<F, E, L>), grid, dim3(WgradB8Cfg<F, E, L>::NTHREADS), 0, st, (const T*)dy, (const T*)tsave,
-                         pb, N, H, W, tiles_x, tiles_x * tiles_y, dy_ls, side_ls);
-  }
-  if (F != 24 || old_b)
+  if (!old_b)
+    hipLaunchKernelGGL((wdsr_wgrad_b8_kernel<F, E, L>), grid, dim3(WgradB8Cfg<F, E, L>::NTHREADS), 0, st, (const T*)dy, (const T*)tsave,
+                       pb, N, H, W, tiles_x, tiles_x * tiles_y, dy_ls, side_ls);
+  if (old_b)
     hipLaunchKernelGGL((wdsr_block_wgrad_saved_kernel<T, F, E, L, 1>), grid, dim3(64 * WgradSavedCfg<F, E, L, 1>::NWAVES), 0, st,
                        (const T*)dy, (const T*)tsave, (const T*)wblob, cinit, pb, N, H, W, tiles_x, tiles_x * tiles_y, dy_ls,
                        side_ls, w_ls, c_ls);

@@ -199,13 +199,13 @@ template <int F, int E, int L> struct WgradB8Cfg {
   typedef BwdCfg<C> B;
   static constexpr int NWAVES = 8, NTHREADS = 64 * NWAVES;
   static constexpr int IMG_ELEMS = (B::NPXC + 1) * 32;                 // t: [core px][32 ch]
-  static constexpr int PXP = 21;                                       // dy pixels per DMA piece (63 chunks + 1 of the next pixel)
+  static constexpr int PXP = 64 / C::FC;                               // dy pixels per DMA piece: 21 (63 chunks + 1 of the next pixel) / 16
   static constexpr int NPD = (C::NPXH + PXP - 1) / PXP;                // dy pieces per tile
   static constexpr int DY_ELEMS = (NPD * PXP + 1) * C::F + 32;         // dy halo tile, rows of F, + the last piece's spill
   static constexpr int NPI = B::NPXC / 16;                             // t pieces per tile (16 px x 4 chunks)
   static constexpr int BUF_ELEMS = IMG_ELEMS + DY_ELEMS;
   static constexpr int LDS_BYTES = 2 * BUF_ELEMS * 2;
-  static_assert(C::FC == 3 && C::NPT_O == 9 && B::NPXC % 16 == 0, "24 units, 12x24 tiles");
+  static_assert((C::FC == 3 || C::FC == 4) && C::NPT_O == 9 && B::NPXC % 16 == 0, "24 or 32 units, 12x24 tiles");
   static_assert(LDS_BYTES >= NWAVES * 2 * 4096, "the epilogue reduces two taps of every wave at a time in the staging buffers");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
@@ -241,8 +241,8 @@ __global__ __launch_bounds__((WgradB8Cfg<F, E, L>::NTHREADS)) void wdsr_wgrad_b8
         const int c = lane & 3, px = p * 16 + (lane >> 2);
         const char* src = c < C::CPT ? reinterpret_cast<const char*>(sp + (size_t)px * C::LP + c * 8) : zeros;
         dma_piece16(src, lds_addr(IMGb) + p * 1024);
-      } else {                                       // dy on the 1-pixel halo: 21 pixels x 3 chunks (+ 1 chunk the next piece rewrites)
-        const int q = p - G::NPI, lq = lane / 3, lc = lane - lq * 3;
+      } else {                                       // dy on the 1-pixel halo: 21 pixels x 3 chunks (+ 1 chunk the next piece rewrites), or 16 x 4
+        const int q = p - G::NPI, lq = lane / C::FC, lc = lane - lq * C::FC;
         const int hp = q * G::PXP + lq;
         const int hy = hp / C::HW, hx = hp - hy * C::HW;
         const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
