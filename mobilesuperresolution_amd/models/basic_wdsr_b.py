@@ -61,8 +61,8 @@ class _DeviceState:
         self.blob_tail = torch.empty(lay.idx_tail.size, dtype=dt, device=device)
         self.packed_key = None                      # (flat.data_ptr(), flat._version) the packed blobs were made from
         self.wgs_body = model.wgs_body
-        self.wgs_tail = int(os.environ.get("SR_WGS_TAIL", 128))
-        self.wgs_head = int(os.environ.get("SR_WGS_HEAD", 128))
+        self.wgs_tail = int(os.environ.get("SR_WGS_TAIL", 256))
+        self.wgs_head = int(os.environ.get("SR_WGS_HEAD", 256))
         self.part_a = f32(lay.NB * self.wgs_body * lay.slab_a)
         self.part_b = f32(lay.NB * self.wgs_body * lay.slab_b)
         self.part_tail = f32(self.wgs_tail * lay.slab_tail)
