@@ -109,6 +109,11 @@ def main():
     ap.add_argument("--force-ddp", action="store_true",
                     help="wrap in DistributedDataParallel even with one rank (measures the DDP/RCCL overhead on one GPU)")
     args = ap.parse_args()
+    # ONE JSON line on stdout: RCCL prints a version banner to the process's stdout (file descriptor 1) when its first
+    # communicator comes up, so fd 1 is pointed at stderr for the run and the line goes to a saved copy of the real stdout
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -355,7 +360,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        print(json.dumps(out), file=real_stdout, flush=True)
     if use_ddp:
         dist.barrier()
         dist.destroy_process_group()

@@ -418,9 +418,15 @@ class BASIC_MODEL(nn.Module):
                 op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
                 h_hi = dist.all_reduce(gflat[k:], op=op, group=pg, async_op=True)     # runs under the early half
                 L.launch("sr_wdsr_net_backward_part", lib.sr_wdsr_net_backward_part, ctypes.byref(net), 2, sp)
-                h_lo = dist.all_reduce(gflat[:k], op=op, group=pg, async_op=True)
-                h_hi.wait()
-                h_lo.wait()                                   # (stream-side waits: the host does not block)
+                # the early half's all-reduce has nothing left to hide under: issued synchronously it is enqueued on THIS
+                # stream (no event hand-off to the collective's own stream and back: ~12 us each way on the GPU timeline)
+                if os.environ.get("SR_DP_LAST_ASYNC") == "1":
+                    h_lo = dist.all_reduce(gflat[:k], op=op, group=pg, async_op=True)
+                    h_hi.wait()
+                    h_lo.wait()                               # (stream-side waits: the host does not block)
+                else:
+                    h_hi.wait()
+                    dist.all_reduce(gflat[:k], op=op, group=pg)
                 if not avg:
                     gflat.div_(dist.get_world_size(pg))
                 L.launch("sr_adam_step", lib.sr_adam_step, flat.data_ptr(), gflat.data_ptr(), state.exp_avg.data_ptr(),
