@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ddp-wrapper", action="store_true",
                     help="N > 1: train through torch's DistributedDataParallel wrapper instead of model.train_step's own all-reduce")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N > 1, fused route: all-reduce the gradient in two halves, the first under the early half's backward "
+                         "(default for this model size: one all-reduce after the backward, which is faster -- DESIGN.md section 6)")
     ap.add_argument("--force-ddp", action="store_true",
                     help="wrap in DistributedDataParallel even with one rank (measures the DDP/RCCL overhead on one GPU)")
     args = ap.parse_args()
@@ -173,7 +176,7 @@ def main():
     pg = dist.group.WORLD if (use_ddp and fused) else None   # --force-ddp on one rank: the data-parallel route all the same
 
     def step():
-        return model.train_step(x, hr, state, process_group=pg) if fused else step_unfused()
+        return model.train_step(x, hr, state, process_group=pg, overlap=(True if args.overlap else None)) if fused else step_unfused()
 
     def sync():
         if use_ddp:
@@ -342,7 +345,8 @@ def main():
             "unit": "HR-Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "step_route": ("model.train_step: loss folded into the tail backward + Adam kernel" +
-                           (", gradient all-reduce (RCCL avg) in two halves overlapped with the backward" if use_ddp else ", one C call"))
+                           ((", gradient all-reduce (avg) in two halves, the first under the early half of the backward" if args.overlap
+                             else ", one gradient all-reduce (avg, 0.77 MB) on the compute stream before the Adam kernel") if use_ddp else ", one C call"))
                           if fused else "DistributedDataParallel wrapper (two gradient segments): forward / F.l1_loss / backward + "
                                         "bucketed all-reduce / torch Adam",
             "per_step_ms": {"n": nd, "median": round(dist_ms[nd // 2], 4), "p10": round(dist_ms[nd // 10], 4),

@@ -345,6 +345,8 @@ class BASIC_MODEL(nn.Module):
                                       "loss (DistributedDataParallel hooks need the two gradient nodes)")
         return _NetLossFunction.apply(x, hr, self.flat, self, kind, float(weight))
 
+    DP_OVERLAP_MIN_PARAMS = 4 * 1024 * 1024
+
     def receptive_halo(self) -> int:
         """LR pixels of context an output pixel depends on, per side: head 3x3 + one 3x3 per block + tail 3x3 (the 5x5 skip
         needs 2) -- what a tile of inference.tiled_forward must carry around its core"""
@@ -363,7 +365,7 @@ class BASIC_MODEL(nn.Module):
         return AdamState(self.flat, lr, betas, eps)
 
     def train_step(self, x: torch.Tensor, hr: torch.Tensor, state: "AdamState", kind: str = "l1", weight: float = 1.0,
-                   process_group=None):
+                   process_group=None, overlap=None):
         """One whole training step -- forward, loss, backward, Adam -- in ONE call into libsr_hotpath.so; `flat` is updated
         in place.  Returns the loss as a device scalar (no host sync; `.item()` it when pretrain.py:82 would).
 
@@ -405,10 +407,28 @@ class BASIC_MODEL(nn.Module):
             pg = dist.group.WORLD
         with torch.cuda.device(x.device):
             sp = L.stream_ptr(x.device)
-            if pg is None or not self.nb_split:
+            # Data-parallel: `overlap` = all-reduce the late half's gradient under the early half's backward.  That costs two
+            # half-depth weight-gradient launches per kernel and a second slab reduction (+29 us at C2) and leaves the second
+            # collective exposed anyway; an all-reduce of C2's 0.77 MB over xGMI is latency-bound (tens of microseconds whatever
+            # its size), so for small models ONE collective after the whole backward is faster.  Default: overlap from 4 M
+            # parameters (16 MB of gradient) on.
+            if overlap is None:
+                overlap = flat.numel() >= self.DP_OVERLAP_MIN_PARAMS
+            if pg is None:
                 L.launch("sr_wdsr_net_train_step", L.lib().sr_wdsr_net_train_step, ctypes.byref(net), state.exp_avg.data_ptr(),
                          state.exp_avg_sq.data_ptr(), flat.numel(), ctypes.byref(scal), float(weight) / out.numel(),
                          loss.data_ptr(), sp)
+            elif not (overlap and self.nb_split):
+                lib = L.lib()
+                L.launch("sr_wdsr_net_forward", lib.sr_wdsr_net_forward, ctypes.byref(net), 1, sp)
+                L.launch("sr_wdsr_net_backward_part", lib.sr_wdsr_net_backward_part, ctypes.byref(net), 0, sp)
+                avg = dist.get_backend(pg) == "nccl"
+                dist.all_reduce(gflat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=pg)   # on this stream
+                if not avg:
+                    gflat.div_(dist.get_world_size(pg))
+                L.launch("sr_adam_step", lib.sr_adam_step, flat.data_ptr(), gflat.data_ptr(), state.exp_avg.data_ptr(),
+                         state.exp_avg_sq.data_ptr(), flat.numel(), ctypes.byref(scal), st.loss_part.data_ptr(), st.wgs_tail,
+                         float(weight) / out.numel(), loss.data_ptr(), sp)
             else:
                 k = lay.split_at(self.nb_split)[0]
                 lib = L.lib()

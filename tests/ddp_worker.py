@@ -16,7 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--mode", default="wrapper", choices=["wrapper", "fused", "nas_phases"])
+    ap.add_argument("--mode", default="wrapper", choices=["wrapper", "fused", "fused_overlap", "nas_phases"])
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group(os.environ.get("SR_DDP_BACKEND", "gloo"), init_method="env://")
@@ -27,8 +27,8 @@ def main():
 
     ns = argparse.Namespace(model_type="BASIC_MODEL", image_mean=0.5, num_channels=3, scale=4, num_blocks=8, num_residual_units=24,
                             hot_dtype=args.dtype, hot_grad_segments=2)
-    if args.mode == "fused":
-        return fused_mode(args, ns, rank, world)
+    if args.mode in ("fused", "fused_overlap"):
+        return fused_mode(args, ns, rank, world, overlap=args.mode == "fused_overlap")
     if args.mode == "nas_phases":
         return nas_phases_mode(args, rank, world)
     torch.manual_seed(0)
@@ -88,7 +88,7 @@ def _single(ref, x, hr, rs):
         d.is_initialized = real
 
 
-def fused_mode(args, ns, rank, world):
+def fused_mode(args, ns, rank, world, overlap=False):
     """model.train_step(..., process_group): every rank steps on its shard; afterwards the replicas are equal and match a
     single process stepping on the whole batch"""
     from mobilesuperresolution_amd.models import get_model
@@ -102,7 +102,8 @@ def fused_mode(args, ns, rank, world):
     losses = []
     batches = [(torch.rand(n, 3, 24, 36, generator=g), torch.rand(n, 3, 96, 144, generator=g)) for _ in range(3)]
     for x, hr in batches:
-        losses.append(m.train_step(x[rank * per:(rank + 1) * per].cuda(), hr[rank * per:(rank + 1) * per].cuda(), st).item())
+        losses.append(m.train_step(x[rank * per:(rank + 1) * per].cuda(), hr[rank * per:(rank + 1) * per].cuda(), st,
+                                   overlap=overlap).item())
     mine = m.flat.detach().cpu()
     gathered = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine)

@@ -64,10 +64,12 @@ def _run_two_ranks(tmp_path, mode):
     return json.load(open(out))
 
 
-def test_fused_data_parallel_train_step_two_ranks(tmp_path):
-    """model.train_step(..., process_group) on two ranks (half batch each, gradient all-reduced in two halves) == one
-    process stepping on the whole batch: replicas stay bit-equal, parameters match the full-batch run"""
-    res = _run_two_ranks(tmp_path, "fused")
+@pytest.mark.parametrize("mode", ["fused", "fused_overlap"])
+def test_fused_data_parallel_train_step_two_ranks(tmp_path, mode):
+    """model.train_step(..., process_group) on two ranks (half batch each; gradient all-reduced once after the backward, or
+    in two halves with the first under the early half of the backward) == one process stepping on the whole batch: replicas
+    stay bit-equal, parameters match the full-batch run"""
+    res = _run_two_ranks(tmp_path, mode)
     assert res["replicas_equal"], res
     assert res["param_err"] <= 2e-5 * res["param_scale"] + 2e-6, res      # Adam's first steps amplify fp32 summation-order ulps
     assert all(abs(a) > 0 for a in res["loss_rank0"])
