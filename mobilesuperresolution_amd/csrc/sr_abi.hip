@@ -9,6 +9,7 @@
 #include "wdsr_prep.h"
 #include "conv3x3.h"
 #include "nas_block.h"
+#include "nas_dw_lc.h"
 #include "flow_warp.h"
 #include "metrics.h"
 #include "patches.h"
@@ -626,6 +627,16 @@ extern "C" int sr_nas_dw_fwd(const void* yin, void* V, const float* dwp, int N, 
   if (!yin || !V || !dwp || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
   hipStream_t st = (hipStream_t)stream;
   const long vs = (long)N * H * W * F;
+  static const bool valu_dw = getenv("SR_NAS_DW_VALU") != nullptr;     // the VALU stencils also in bf16 mode (A/B measurements)
+  if (dtype == SR_DTYPE_BF16 && !valu_dw && (F == 24 || F == 32)) {      // lane = channel, packed bf16 dot products (csrc/nas_dw_lc.h)
+    typedef NasCfg<24> C;
+    const int tx = (W + C::TW - 1) / C::TW;
+    dim3 g(tx * ((H + C::TH - 1) / C::TH), N);
+    if (F == 24) hipLaunchKernelGGL((nas_dw_fwd_lc_kernel<24>), g, dim3(512), 0, st, (const __bf16*)yin, (__bf16*)V, dwp, H, W, tx, vs);
+    else hipLaunchKernelGGL((nas_dw_fwd_lc_kernel<32>), g, dim3(512), 0, st, (const __bf16*)yin, (__bf16*)V, dwp, H, W, tx, vs);
+    SR_HIP_CHECK_LAUNCH();
+    return 0;
+  }
 #define CALL(T, F_) { typedef NasCfg<F_> C; const int tx = (W + C::TW - 1) / C::TW; dim3 g(tx * ((H + C::TH - 1) / C::TH), N); \
     hipLaunchKernelGGL((nas_dw_fwd_kernel<T, F_>), g, dim3(512), 0, st, (const T*)yin, (T*)V, dwp, H, W, tx, vs); }
   SR_NAS_DISPATCH(CALL)
@@ -663,6 +674,15 @@ extern "C" int sr_nas_dw_bwd(const void* yin, const void* GZ, const void* gy, vo
   if (!yin || !GZ || !gy || !gyin || !dwp || !partial || wgs <= 0 || N <= 0 || H <= 0 || W <= 0) return -2;
   hipStream_t st = (hipStream_t)stream;
   const long vs = (long)N * H * W * F;
+  static const bool valu_dw = getenv("SR_NAS_DW_VALU") != nullptr;
+  if (dtype == SR_DTYPE_BF16 && !valu_dw && (F == 24 || F == 32)) {      // lane = channel (csrc/nas_dw_lc.h); the dW part of the slab is sr_nas_dw_wgrad's
+    typedef NasCfg<24> C;
+    const int tx = (W + C::TW - 1) / C::TW, tpi = tx * ((H + C::TH - 1) / C::TH);
+    if (F == 24) hipLaunchKernelGGL((nas_dw_bwd_lc_kernel<24>), dim3(wgs), dim3(512), 0, st, (const __bf16*)yin, (const __bf16*)GZ, (const __bf16*)gy, (__bf16*)gyin, dwp, partial, N, H, W, tx, tpi, vs);
+    else hipLaunchKernelGGL((nas_dw_bwd_lc_kernel<32>), dim3(wgs), dim3(512), 0, st, (const __bf16*)yin, (const __bf16*)GZ, (const __bf16*)gy, (__bf16*)gyin, dwp, partial, N, H, W, tx, tpi, vs);
+    SR_HIP_CHECK_LAUNCH();
+    return 0;
+  }
 #define CALL(T, F_) { typedef NasCfg<F_> C; const int tx = (W + C::TW - 1) / C::TW, tpi = tx * ((H + C::TH - 1) / C::TH); \
     hipLaunchKernelGGL((nas_dw_bwd_kernel<T, F_>), dim3(wgs), dim3(512), 0, st, (const T*)yin, (const T*)GZ, (const T*)gy, (T*)gyin, dwp, partial, N, H, W, tx, tpi, vs); }
   SR_NAS_DISPATCH(CALL)

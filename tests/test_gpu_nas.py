@@ -112,3 +112,43 @@ def test_nas_model_matches_oracle_glue(training):
         worst = max(worst, ge)
         assert ge <= 5e-4, (k, ge)
     print(f"NAS model worst param-grad rel err {worst:.2e}")
+
+
+@pytest.mark.parametrize("units", [24, 32])
+def test_nas_bf16_mode_tracks_fp32_mode(units):
+    """throughput mode of the supernet (bf16 activations, depthwise stencils on packed bf16 dot products with lane = channel,
+    pointwise convs on the matrix cores) against the exact fp32 mode on the same parameters: output and every gradient
+    within bf16 tolerance, ragged image, masks partly off, one skipped block"""
+    from mobilesuperresolution_amd.models import get_model
+    torch.manual_seed(9)
+    a = get_model(_nas_ns(num_residual_units=units, hot_dtype="fp32"))
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        a.mask.weight.copy_(torch.rand(units, 1, 1, 1, generator=g) * 0.7 + 0.25)
+        for blk in a.body:
+            blk.split.weight.copy_(torch.rand(units, 1, 1, 1, generator=g) * 0.7 + 0.2)
+    b = get_model(_nas_ns(num_residual_units=units, hot_dtype="bf16"))
+    b.load_state_dict(a.state_dict())
+    a, b = a.cuda().train(), b.cuda().train()
+    x = torch.rand(2, 3, 29, 50, generator=g).cuda()
+    hr = torch.rand(2, 3, 116, 200, generator=g).cuda()
+    outs = []
+    for m in (a, b):
+        out, speed = m(x)
+        (torch.nn.functional.l1_loss(out, hr) + 0.1 * speed.sum()).backward()
+        outs.append((out.detach(), speed.detach()))
+    rel = ((outs[1][0] - outs[0][0]).norm() / outs[0][0].norm()).item()
+    assert rel <= 2e-2, rel
+    assert abs(outs[1][1].item() - outs[0][1].item()) <= 1e-5 * abs(outs[0][1].item())
+    ga, gb = a.flat.grad, b.flat.grad
+    grel = ((gb - ga).norm() / ga.norm()).item()
+    print(f"\nNAS F={units} bf16 vs fp32 mode: out rel L2 {rel:.2e}, flat grad rel L2 {grel:.2e}")
+    assert grel <= 6e-2, grel
+    worst = 0.0
+    for (k, pa), (_, pb) in zip(a.named_reference_tensors(grads=True), b.named_reference_tensors(grads=True)):
+        if pa is None or float(pa.abs().max()) == 0.0:
+            continue
+        e = ((pb - pa).norm() / pa.norm()).item()
+        worst = max(worst, e)
+        assert e <= 0.15, (k, e)
+    print(f"worst per-tensor grad rel L2 {worst:.2e}")
