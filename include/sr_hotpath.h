@@ -237,6 +237,19 @@ int sr_nas_dw_bwd(const void* yin, const void* GZ, const void* gy, void* gyin, c
 int sr_nas_dw_wgrad(const void* yin, const void* GZ, const float* dwp, float* partial, int wgs, int N, int H, int W,
                     int F, int dtype, sr_stream_t stream);
 
+/* Every block of the supernet body from one call each way (the per-op entry points above, looped in C: 2 launches per
+ * block forward, 3 backward).  ys [(nb+1)][N][H][W][F] (slot 0 = input, slot nb = output); V [nb][3][N][H][W][F];
+ * per-block tables at BYTE strides: dwp (dwp_bs), frags (frags_bs), tabs (tabs_bs), scal (scal_bs).  Backward: g_out =
+ * gradient at ys[nb]; g_tmp[2] two activation-sized scratch buffers; GZ [3][N][H][W][F] scratch; part_pw / part_dw
+ * [nb][wgs][slab] at byte strides pw_bs / dw_bs.  *g_in receives the pointer (g_tmp[0] or g_tmp[1]) that holds the gradient at ys[0]. */
+int sr_nas_body_fwd(void* ys, void* V, const float* dwp, long dwp_bs, const void* frags, long frags_bs, const float* tabs,
+                    long tabs_bs, const float* scal, long scal_bs, int nb, int N, int H, int W, int F, int dtype,
+                    sr_stream_t stream);
+int sr_nas_body_bwd(const void* ys, const void* V, const void* g_out, void* g_tmp0, void* g_tmp1, void* GZ, const float* dwp,
+                    long dwp_bs, const void* frags, long frags_bs, const float* tabs, long tabs_bs, const float* scal,
+                    long scal_bs, float* part_pw, long pw_bs, float* part_dw, long dw_bs, int wgs, int nb, int N, int H, int W,
+                    int F, int dtype, void** g_in, sr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Whole-network entry points: everything BASIC_MODEL.forward (models/basic_wdsr_b.py:85-93) and its
  * autograd backward do, as ONE call each.  The caller (mobilesuperresolution_amd/models) owns every

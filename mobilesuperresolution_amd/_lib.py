@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SR_HOTPATH_LIB_PATH (tools/ only): an explicitly named build of the same sources (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("SR_HOTPATH_LIB_PATH") or os.path.join(
     _HERE, "libsr_hotpath_dbg.so" if os.environ.get("SR_HOTPATH_DEBUG_LIB") == "1" else "libsr_hotpath.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
 
 _P, _I, _Z, _L, _F = c_void_p, c_int, c_size_t, ctypes.c_long, ctypes.c_float
@@ -53,6 +53,8 @@ SIGNATURES = {
     "sr_nas_pw_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_nas_dw_bwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_patch_gather": ([_P, _P, _P, _P, _I, _I, _I, _P], _I),
+    "sr_nas_body_fwd": ([_P, _P, _P, _L, _P, _L, _P, _L, _P, _L] + [_I] * 6 + [_P], _I),
+    "sr_nas_body_bwd": ([_P] * 7 + [_L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L] + [_I] * 7 + [_P, _P], _I),
     "sr_psnr": ([_P, _P, _P, _P] + [_I] * 7 + [_P], _I),
     "sr_pixel_shuffle": ([_P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_tail_bwd_loss": ([_P, _P, _I, _F, _P, _P, _P, _F, _P, _P, _P] + [_I] * 7 + [_P], _I),

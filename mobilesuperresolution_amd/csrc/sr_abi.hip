@@ -16,7 +16,7 @@
 #include "train_step.h"
 #include "pixel_shuffle.h"
 
-extern "C" int sr_abi_version(void) { return 5; }
+extern "C" int sr_abi_version(void) { return 6; }
 
 namespace {
 
@@ -929,6 +929,51 @@ extern "C" int sr_wdsr_net_backward_part(const sr_wdsr_net_t* n, int part, sr_st
 }
 
 extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) { return sr_wdsr_net_backward_part(n, 0, stream); }
+
+// every block of the supernet body from one call each way
+extern "C" int sr_nas_body_fwd(void* ys, void* V, const float* dwp, long dwp_bs, const void* frags, long frags_bs, const float* tabs,
+                               long tabs_bs, const float* scal, long scal_bs, int nb, int N, int H, int W, int F, int dtype,
+                               sr_stream_t stream) {
+  if (!ys || !V || !dwp || !frags || !tabs || !scal || nb <= 0 || N <= 0 || H <= 0 || W <= 0) return -2;
+  const size_t act = (size_t)N * H * W * F * (dtype == SR_DTYPE_BF16 ? 2 : 4);
+  for (int i = 0; i < nb; ++i) {
+    char* yi = (char*)ys + (size_t)i * act;
+    char* Vi = (char*)V + (size_t)i * 3 * act;
+    int rc;
+    if ((rc = sr_nas_dw_fwd(yi, Vi, (const float*)((const char*)dwp + (size_t)i * dwp_bs), N, H, W, F, dtype, stream))) return rc;
+    if ((rc = sr_nas_pw_fwd(yi, Vi, yi + act, (const char*)frags + (size_t)i * frags_bs, (const float*)((const char*)tabs + (size_t)i * tabs_bs),
+                            (const float*)((const char*)scal + (size_t)i * scal_bs), N, H, W, F, dtype, stream)))
+      return rc;
+  }
+  return 0;
+}
+extern "C" int sr_nas_body_bwd(const void* ys, const void* V, const void* g_out, void* g_tmp0, void* g_tmp1, void* GZ, const float* dwp,
+                               long dwp_bs, const void* frags, long frags_bs, const float* tabs, long tabs_bs, const float* scal,
+                               long scal_bs, float* part_pw, long pw_bs, float* part_dw, long dw_bs, int wgs, int nb, int N, int H,
+                               int W, int F, int dtype, void** g_in, sr_stream_t stream) {
+  if (!ys || !V || !g_out || !g_tmp0 || !g_tmp1 || !GZ || !dwp || !frags || !tabs || !scal || !part_pw || !part_dw || !g_in || wgs <= 0 ||
+      nb <= 0 || N <= 0 || H <= 0 || W <= 0)
+    return -2;
+  const size_t act = (size_t)N * H * W * F * (dtype == SR_DTYPE_BF16 ? 2 : 4);
+  const void* g = g_out;
+  for (int i = nb - 1; i >= 0; --i) {
+    void* gin = (i & 1) ? g_tmp1 : g_tmp0;
+    const char* yi = (const char*)ys + (size_t)i * act;
+    const char* Vi = (const char*)V + (size_t)i * 3 * act;
+    const float* dw_i = (const float*)((const char*)dwp + (size_t)i * dwp_bs);
+    float* pdw = (float*)((char*)part_dw + (size_t)i * dw_bs);
+    int rc;
+    if ((rc = sr_nas_pw_bwd(yi, Vi, g, GZ, (const char*)frags + (size_t)i * frags_bs, (const float*)((const char*)tabs + (size_t)i * tabs_bs),
+                            (const float*)((const char*)scal + (size_t)i * scal_bs), (float*)((char*)part_pw + (size_t)i * pw_bs), wgs, N,
+                            H, W, F, dtype, stream)))
+      return rc;
+    if ((rc = sr_nas_dw_bwd(yi, GZ, g, gin, dw_i, pdw, wgs, N, H, W, F, dtype, stream))) return rc;
+    if ((rc = sr_nas_dw_wgrad(yi, GZ, dw_i, pdw, wgs, N, H, W, F, dtype, stream))) return rc;
+    g = gin;
+  }
+  *g_in = const_cast<void*>(g);
+  return 0;
+}
 
 // ------------------------------------------------------------------------------------------
 // standalone PixelShuffle

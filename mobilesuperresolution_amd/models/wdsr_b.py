@@ -195,14 +195,10 @@ class _NasBodyFunction(torch.autograd.Function):
         ys = torch.empty((nb + 1, n, h, w, f), dtype=dt, device=dev)
         ys[0] = y0
         V = torch.empty((nb, 3, n, h, w, f), dtype=dt, device=dev)
-        sp, lib = L.stream_ptr(), L.lib()                    # one stream lookup per call, not per launch
-        ysp, Vp, dwpp, frp, tbp, scp = (t.data_ptr() for t in (ys, V, dwp, frags, tabs, scal))
-        ysz, Vsz = ys[0].numel() * ys.element_size(), V[0].numel() * V.element_size()
-        dsz, fsz, tsz, ssz = (t.stride(0) * t.element_size() for t in (dwp, frags, tabs, scal))
-        for i in range(nb):
-            L.launch("sr_nas_dw_fwd", lib.sr_nas_dw_fwd, ysp + i * ysz, Vp + i * Vsz, dwpp + i * dsz, n, h, w, f, code, sp)
-            L.launch("sr_nas_pw_fwd", lib.sr_nas_pw_fwd, ysp + i * ysz, Vp + i * Vsz, ysp + (i + 1) * ysz,
-                     frp + i * fsz, tbp + i * tsz, scp + i * ssz, n, h, w, f, code, sp)
+        L.launch("sr_nas_body_fwd", L.lib().sr_nas_body_fwd, ys.data_ptr(), V.data_ptr(), dwp.data_ptr(),
+                 dwp.stride(0) * dwp.element_size(), frags.data_ptr(), frags.stride(0) * frags.element_size(), tabs.data_ptr(),
+                 tabs.stride(0) * tabs.element_size(), scal.data_ptr(), scal.stride(0) * scal.element_size(), nb, n, h, w, f, code,
+                 L.stream_ptr())                              # every block from ONE C call (2 launches per block)
         ctx.save_for_backward(ys, V, dwp, frags, tabs, scal, MSf, P.detach().float(), BETA.detach().float())
         return ys[nb]
 
@@ -219,19 +215,14 @@ class _NasBodyFunction(torch.autograd.Function):
         part_dw = torch.empty((nb, wgs, tb["dw_slab"]), dtype=torch.float32, device=dev)
         g = gy.contiguous()
         gbuf = [torch.empty_like(g), torch.empty_like(g)]
-        sp, lib = L.stream_ptr(), L.lib()
-        ysp, Vp, dwpp, frp, tbp, scp, ppw, pdw, GZp = (t.data_ptr() for t in (ys, V, dwp, frags, tabs, scal, part_pw, part_dw, GZ))
-        ysz, Vsz = ys[0].numel() * ys.element_size(), V[0].numel() * V.element_size()
-        dsz, fsz, tsz, ssz, pwz, dwz = (t.stride(0) * t.element_size() for t in (dwp, frags, tabs, scal, part_pw, part_dw))
-        for i in range(nb - 1, -1, -1):
-            gin = gbuf[i & 1]
-            gp, ginp = g.data_ptr(), gin.data_ptr()
-            L.launch("sr_nas_pw_bwd", lib.sr_nas_pw_bwd, ysp + i * ysz, Vp + i * Vsz, gp, GZp, frp + i * fsz, tbp + i * tsz,
-                     scp + i * ssz, ppw + i * pwz, wgs, n, h, w, f, code, sp)
-            L.launch("sr_nas_dw_bwd", lib.sr_nas_dw_bwd, ysp + i * ysz, GZp, gp, ginp, dwpp + i * dsz, pdw + i * dwz, wgs, n, h, w, f,
-                     code, sp)
-            L.launch("sr_nas_dw_wgrad", lib.sr_nas_dw_wgrad, ysp + i * ysz, GZp, dwpp + i * dsz, pdw + i * dwz, wgs, n, h, w, f, code, sp)
-            g = gin
+        import ctypes
+        g_in = ctypes.c_void_p()
+        L.launch("sr_nas_body_bwd", L.lib().sr_nas_body_bwd, ys.data_ptr(), V.data_ptr(), g.data_ptr(), gbuf[0].data_ptr(),
+                 gbuf[1].data_ptr(), GZ.data_ptr(), dwp.data_ptr(), dwp.stride(0) * dwp.element_size(), frags.data_ptr(),
+                 frags.stride(0) * frags.element_size(), tabs.data_ptr(), tabs.stride(0) * tabs.element_size(), scal.data_ptr(),
+                 scal.stride(0) * scal.element_size(), part_pw.data_ptr(), part_pw.stride(0) * 4, part_dw.data_ptr(),
+                 part_dw.stride(0) * 4, wgs, nb, n, h, w, f, code, ctypes.byref(g_in), L.stream_ptr())   # 3 launches per block
+        g = gbuf[0] if g_in.value == gbuf[0].data_ptr() else gbuf[1]
         spw, sdw = part_pw.sum(1), part_dw.sum(1)                                      # (nb, slab)
         g_wpw = spw.index_select(1, tb["g_wpw"]).view(nb, 3, f, f, 1, 1)
         g_bpw = spw.index_select(1, tb["g_bpw"]).view(nb, 3, f)
