@@ -139,6 +139,36 @@ SR_DEV void nas_stage_vt(T* VT, const T* __restrict__ v, int H, int W, int ty0, 
   }
 }
 
+// core tiles of the three V_k as [3][NPXC + 1][32], loads issued in batches before their stores (a load / store loop
+// compiles to one memory round trip per chunk and thread)
+template <typename T, typename C, int NTHREADS>
+SR_DEV void nas_stage_vt3(T* VT, const T* __restrict__ v, long vstride, int H, int W, int ty0, int tx0, int tid) {
+  typedef typename FragOf<T>::type FragT;
+  constexpr int PER = (C::NPXC + 1) * 4, TOTAL = 3 * PER, IT = (TOTAL + NTHREADS - 1) / NTHREADS, B = sizeof(T) == 2 ? 3 : 4;
+#pragma unroll 1
+  for (int base = 0; base < IT; base += B) {
+    FragT f[B];
+#pragma unroll
+    for (int it = 0; it < B; ++it) {
+      const int idx = tid + (base + it) * NTHREADS;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[it][j] = (T)0.f;
+      if (base + it < IT && idx < TOTAL) {
+        const int kk = idx / PER, q = idx - kk * PER, pc = q >> 2, c = q & 3;
+        if (pc < C::NPXC && c < C::FC) {
+          const int Y = ty0 + pc / C::TW, X = tx0 + pc % C::TW;
+          if (Y < H && X < W) f[it] = *reinterpret_cast<const FragT*>(v + kk * vstride + ((size_t)Y * W + X) * C::F + c * 8);
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < B; ++it) {
+      const int idx = tid + (base + it) * NTHREADS;
+      if (base + it < IT && idx < TOTAL) *reinterpret_cast<FragT*>(VT + (size_t)idx * 8) = f[it];
+    }
+  }
+}
+
 // 16 accumulator-layout values (rows = channels 8g + 4hh + j) of pixel `px` from an NHWC tensor; rows >= F are 0
 template <typename T, int F> SR_DEV void nas_load_rows(float (&out)[16], const T* __restrict__ p, int hh) {
   typedef typename FragOf<T>::half_type HalfT;
@@ -212,50 +242,99 @@ __global__ __launch_bounds__(576) void nas_pw_fwd_kernel(const T* __restrict__ y
 // ---------------------------------------------------------------------------------------------
 // pointwise backward: recompute u_k; gu_k = p_k beta2 ms gy 1(u_k>0); GZ_k = (Wpw_k^T gu_k) 1(V_k>0);
 // per-branch slabs: dWpw_k [co rows, ci cols], dbp_k = sum gu_k, r_k[c] = sum gy[c] relu(u_k)[c]; scalar
-// sxy = sum gy * mg * yin.  Wave (k, grp) owns branch k and pixel tiles grp, grp+2, ... (6 waves).
+// sxy = sum gy * mg * yin.  Wave (k, grp) owns branch k and pixel tiles grp, grp+GW, ... (3 x GW waves).
 // frags: 6 forward + 6 backward (rows ci, k = co chained).  grid = (wgs), persistent over tiles.
 // ---------------------------------------------------------------------------------------------
+// 3 branches x GW waves: the 27 (branch, pixel tile) items of a tile in two rounds (15 waves) instead of five (6 waves, round 1)
+#ifndef NAS_PWB_GW_BF16
+#define NAS_PWB_GW_BF16 4
+#endif
+template <typename T> struct NasPwb {                 // fp32 (parity mode): the staged tiles are twice as large, LDS holds scratch for 6 waves
+  static constexpr int GW = sizeof(T) == 2 ? NAS_PWB_GW_BF16 : 2, THREADS = 3 * GW * 64;
+};
 template <typename T, int F>
-__global__ __launch_bounds__(384) void nas_pw_bwd_kernel(const T* __restrict__ yin, const T* __restrict__ V,
+__global__ __launch_bounds__(NasPwb<T>::THREADS) void nas_pw_bwd_kernel(const T* __restrict__ yin, const T* __restrict__ V,
                                                          const T* __restrict__ gy, T* __restrict__ GZ,
                                                          const T* __restrict__ frags, const float* __restrict__ tabs,
                                                          const float* __restrict__ scal, float* __restrict__ partial,
                                                          int N, int H, int W, int tiles_x, int tiles_per_img, long vstride) {
   typedef NasCfg<F> C;
+  constexpr int NAS_PWB_GW = NasPwb<T>::GW, NAS_PWB_THREADS = NasPwb<T>::THREADS;
   typedef typename FragOf<T>::half_type HalfT;
   constexpr int SCR = 33 * 32;
-  constexpr int STAGE_BYTES = (3 * C::VT_ELEMS + 6 * SCR) * (int)sizeof(T);
-  constexpr int LDS_BYTES = STAGE_BYTES > C::PWB_SLAB * 4 ? STAGE_BYTES : C::PWB_SLAB * 4;
+  constexpr int WL_OFF = (3 * C::VT_ELEMS + 3 * NAS_PWB_GW * SCR) * (int)sizeof(T);     // 12 weight fragments
+  constexpr int TB_OFF = WL_OFF + 12 * 512 * (int)sizeof(T);                             // bp[3][32] | ms | mg (C-init layout)
+  constexpr int STAGE_BYTES = TB_OFF + 160 * 4;
+  static_assert((3 * NAS_PWB_GW * C::PWB_K + 16) * 4 <= WL_OFF, "the per-wave slab copies overlay the V tiles only");
+  constexpr int LDS_BYTES = STAGE_BYTES;
   __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES];
   T* const VT = reinterpret_cast<T*>(smem_raw);
+  const T* const WL = reinterpret_cast<const T*>(smem_raw + WL_OFF);
+  const float* const TB = reinterpret_cast<const float*>(smem_raw + TB_OFF);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   T* const scr = VT + 3 * C::VT_ELEMS + wave * SCR;
-  const int k = wave >> 1, grp = wave & 1;          // 6 waves: (branch, pixel-tile parity)
+  const int k = wave / NAS_PWB_GW, grp = wave - k * NAS_PWB_GW;          // 3 x GW waves: (branch, pixel-tile residue)
   const T* const VTk = VT + k * C::VT_ELEMS;
+  SR_STAMP_DECL;
+  SR_STAMP();
   f32x16 dW = zero16();
   float db[16], rk[16], sxy = 0.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { db[i] = 0.f; rk[i] = 0.f; }
-  const float coef = scal[k] * scal[3];                        // p_k * beta2
 
   for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
     const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
     const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
     const size_t img = (size_t)n * H * W * F;
     __syncthreads();
+    nas_stage_vt3<T, C, NAS_PWB_THREADS>(VT, V + img, vstride, H, W, ty0, tx0, tid);
+    if (t == (int)blockIdx.x) {
+      // weights and tables once per workgroup, read from LDS at each use (held in registers they cost a wave per SIMD).
+      // The backward fragments (rows ci, k = co) are scaled along k by c_k[co] = p_k beta2 ms[co] on the way: the
+      // item loop then works with m = gy 1(u > 0) instead of gu = c_k m (exact in bf16, and no table in registers):
+      // GZ = (Wpw^T diag(c_k)) m, dWpw = diag(c_k) (m^T v), dbp = c_k sum m -- the last two scaled once in the epilogue.
+      typedef typename FragOf<T>::type FragT;
+      const float b2 = scal[3];
+      for (int i = tid; i < 12 * 64; i += NAS_PWB_THREADS) {
+        FragT v = reinterpret_cast<const FragT*>(frags)[i];
+        const int f = i >> 6, l = i & 63;
+        if (f >= 6) {
+          const int kk = (f - 6) >> 1, st = (f - 6) & 1;
+          const float pk = (kk == 0 ? scal[0] : (kk == 1 ? scal[1] : scal[2])) * b2;
 #pragma unroll
-    for (int kk = 0; kk < 3; ++kk) nas_stage_vt<T, C, 384>(VT + kk * C::VT_ELEMS, V + kk * vstride + img, H, W, ty0, tx0, tid);
+          for (int j = 0; j < 8; ++j) v[j] = (T)((float)v[j] * pk * tabs[96 + (l >> 5) * 16 + 8 * st + j]);
+        }
+        reinterpret_cast<FragT*>(smem_raw + WL_OFF)[i] = v;
+      }
+      if (tid < 160) reinterpret_cast<float*>(smem_raw + TB_OFF)[tid] = tabs[tid];
+    }
     __syncthreads();
-    const T* fr = weights_for_tile<false>(frags);
+    SR_STAMP();
+    const T* fr = WL;
+    // sxy = sum gy mg yin: its own short pass over (pixel, 8-channel chunk) items, all waves (inside the item loop its
+    // operands cost one branch's waves 32 more registers; the gy lines it touches are the ones the items read next)
+    for (int idx = tid; idx < C::NPXC * C::FC; idx += NAS_PWB_THREADS) {
+      typedef typename FragOf<T>::type FragT;
+      const int pcx = idx / C::FC, c = idx - pcx * C::FC;
+      const int Y = ty0 + pcx / C::TW, X = tx0 + pcx % C::TW;
+      if (Y < H && X < W) {
+        const size_t oo = img + ((size_t)Y * W + X) * F + c * 8;
+        const FragT a = *reinterpret_cast<const FragT*>(gy + oo), b = *reinterpret_cast<const FragT*>(yin + oo);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sxy += (float)a[j] * TB[128 + (j >> 2) * 16 + 4 * c + (j & 3)] * (float)b[j];
+      }
+    }
+    SR_STAMP();
+    // pixel tiles of wave (k, grp): ot = grp - k (mod GW), + GW, ...: the waves that take the extra tile sit on different SIMDs
 #pragma unroll 1
-    for (int ot = grp; ot < C::NPT_O; ot += 2) {
+    for (int ot = (grp + NAS_PWB_GW - k % NAS_PWB_GW) % NAS_PWB_GW; ot < C::NPT_O; ot += NAS_PWB_GW) {
       const int toy = (ot / (C::TW / 8)) * 4, tox = (ot % (C::TW / 8)) * 8;
       const int oy = toy + (r >> 3), ox = tox + (r & 7);
       const int pc = oy * C::TW + ox;
       const int Y = ty0 + oy, X = tx0 + ox;
       const bool valid = Y < H && X < W;
       const size_t o = img + ((size_t)(valid ? Y : 0) * W + (valid ? X : 0)) * F;
-      f32x16 acc = load_cinit(tabs + k * 32, hh);
+      f32x16 acc = load_cinit(TB + k * 32, hh);
 #pragma unroll
       for (int s = 0; s < 2; ++s) acc = mma16<T>(load_wfrag<T>(fr, 2 * k + s, lane), lds_chunk<T>(VTk, pc * 32 + (2 * s + hh) * 8), acc);
       float g[16];
@@ -264,27 +343,20 @@ __global__ __launch_bounds__(384) void nas_pw_bwd_kernel(const T* __restrict__ y
 #pragma unroll
         for (int i = 0; i < 16; ++i) g[i] = 0.f;
       }
-      if (k == 0) {
-        float xin[16];
-        nas_load_rows<T, F>(xin, yin + o, hh);
-        const f32x16 mg = load_cinit(tabs + 128, hh);
+      f32x16 gu;                                       // m = gy 1(u > 0); relu(u) gy = m u
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sxy += g[i] * mg[i] * xin[i];
+      for (int i = 0; i < 16; ++i) {
+        gu[i] = acc[i] > 0.f ? g[i] : 0.f;
+        rk[i] += gu[i] * acc[i];
+        db[i] += gu[i];
       }
-      f32x16 gu;
-      {
-        const f32x16 ms = load_cinit(tabs + 96, hh);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          rk[i] += g[i] * fmaxf(acc[i], 0.f);
-          gu[i] = acc[i] > 0.f ? coef * ms[i] * g[i] : 0.f;
-          db[i] += gu[i];
-        }
-      }
-      // d(loss)/d(dw_k output) = (Wpw_k^T gu) * 1(v_k > 0), rows ci
+      // m leaves the registers first (fragments for the data gradient, pixel-major scratch for the weight gradient)
+      const typename FragOf<T>::type gu0 = acc_to_frag<T, 0>(gu), gu1 = acc_to_frag<T, 1>(gu);
+      scratch_store<T>(scr, gu, true, r, hh);
+      // d(loss)/d(dw_k output) = (Wpw_k^T c_k m) * 1(v_k > 0), rows ci
       f32x16 gv = zero16();
-      gv = mma16<T>(load_wfrag<T>(fr, 6 + 2 * k, lane), acc_to_frag<T, 0>(gu), gv);
-      gv = mma16<T>(load_wfrag<T>(fr, 6 + 2 * k + 1, lane), acc_to_frag<T, 1>(gu), gv);
+      gv = mma16<T>(load_wfrag<T>(fr, 6 + 2 * k, lane), gu0, gv);
+      gv = mma16<T>(load_wfrag<T>(fr, 6 + 2 * k + 1, lane), gu1, gv);
       if (valid) {
 #pragma unroll
         for (int gq = 0; gq < C::FC; ++gq) {
@@ -296,29 +368,50 @@ __global__ __launch_bounds__(384) void nas_pw_bwd_kernel(const T* __restrict__ y
         }
       }
       // dWpw_k[co, ci] += sum_px gu[px, co] v_k[px, ci]
-      scratch_store<T>(scr, gu, true, r, hh);
       auto rows = [](int p) { return p * 32; };
       auto rowv = [=](int p) { return ((toy + (p >> 3)) * C::TW + tox + (p & 7)) * 32; };
       dW = mma16<T>(tr_frag<T>(scr, 0, lane, rows), tr_frag<T>(VTk, 0, lane, rowv), dW);
       dW = mma16<T>(tr_frag<T>(scr, 1, lane, rows), tr_frag<T>(VTk, 1, lane, rowv), dW);
     }
   }
-  __syncthreads();
-  float* slab = reinterpret_cast<float*>(smem_raw);
-  for (int i = tid; i < C::PWB_SLAB; i += 384) slab[i] = 0.f;
-  __syncthreads();
-  float* sk = slab + k * C::PWB_K;
-  slab_add_tile(sk, 0, dW, lane);
+  SR_STAMP();
+  if ((int)blockIdx.x < N * tiles_per_img) {          // (a workgroup without tiles staged no table: its sums are zero, 0 x stale LDS may not be)
+    const f32x16 ms = load_cinit(TB + 96, hh);
+    const float ck = scal[k] * scal[3];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-    const float a = half_sum(db[i]), b = half_sum(rk[i]);
-    if (r == 0) { atomicAdd(sk + 1024 + row, a); atomicAdd(sk + 1024 + 32 + row, b); }
+    for (int i = 0; i < 16; ++i) { const float c = ck * ms[i]; dW[i] *= c; db[i] *= c; }
   }
-  { const float v = wave_sum(sxy); if (k == 0 && lane == 0) atomicAdd(slab + 3 * C::PWB_K, v); }
+  const float red = half_sum32(db, rk, r);             // lane r: db[r] (r < 16) or rk[r - 16], summed over the half's pixels
+  const float sxy_w = wave_sum(sxy);
   __syncthreads();
+  SR_STAMP();
+  // every wave writes its own copy of its branch's slab (plain stores, no turns: LDS float atomics cost ~1500 cycles per
+  // wave-instruction on gfx950, and a read-modify-write chain through may-alias LDS pointers ~3 us per wave); the
+  // GW copies of a branch are summed on the way out
+  float* const slab = reinterpret_cast<float*>(smem_raw);
+  float* const sw = slab + wave * C::PWB_K;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sw[i * 64 + lane] = dW[i];
+  { const int i = r & 15; sw[1024 + 2 * (r & 16) + (i & 3) + 8 * (i >> 2) + 4 * hh] = red; }
+  float* const sx = slab + 3 * NAS_PWB_GW * C::PWB_K;
+  if (lane == 0) sx[wave] = sxy_w;
+  __syncthreads();
+  SR_STAMP();
   float* out = partial + (size_t)blockIdx.x * C::PWB_SLAB;
-  for (int i = tid; i < C::PWB_SLAB; i += 384) out[i] = slab[i];
+  for (int i = tid; i < 3 * C::PWB_K; i += NAS_PWB_THREADS) {
+    const int kk = i / C::PWB_K, e = i - kk * C::PWB_K;
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < NAS_PWB_GW; ++g) v += slab[(kk * NAS_PWB_GW + g) * C::PWB_K + e];
+    out[i] = v;
+  }
+  if (tid < 4) {
+    float v = 0.f;
+    if (tid == 0)
+      for (int w = 0; w < 3 * NAS_PWB_GW; ++w) v += sx[w];
+    out[3 * C::PWB_K + tid] = v;
+  }
+  SR_STAMP();
 }
 
 // ---------------------------------------------------------------------------------------------

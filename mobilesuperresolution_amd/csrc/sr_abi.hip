@@ -663,7 +663,7 @@ extern "C" int sr_nas_pw_bwd(const void* yin, const void* V, const void* gy, voi
   hipStream_t st = (hipStream_t)stream;
   const long vs = (long)N * H * W * F;
 #define CALL(T, F_) { typedef NasCfg<F_> C; const int tx = (W + C::TW - 1) / C::TW, tpi = tx * ((H + C::TH - 1) / C::TH); \
-    hipLaunchKernelGGL((nas_pw_bwd_kernel<T, F_>), dim3(wgs), dim3(384), 0, st, (const T*)yin, (const T*)V, (const T*)gy, (T*)GZ, (const T*)frags, tabs, scal, partial, N, H, W, tx, tpi, vs); }
+    hipLaunchKernelGGL((nas_pw_bwd_kernel<T, F_>), dim3(wgs), dim3(NasPwb<T>::THREADS), 0, st, (const T*)yin, (const T*)V, (const T*)gy, (T*)GZ, (const T*)frags, tabs, scal, partial, N, H, W, tx, tpi, vs); }
   SR_NAS_DISPATCH(CALL)
 #undef CALL
   SR_HIP_CHECK_LAUNCH();

@@ -248,6 +248,30 @@ SR_DEV float half_sum(float v) {
   return v;
 }
 
+// 32 per-lane partial sums (a[0..15], b[0..15]) -> their totals over the 32 lanes of each wave half, one per lane:
+// lane r of a half ends up with total #r (r < 16: a[r], else b[r - 16]).  A halving butterfly: at distance 16, 8, .. 1
+// a lane keeps the half of the values its bit selects and hands the other half to its partner: 31 exchanges instead
+// of the 160 of 32 separate half_sum() calls (each a ds_bpermute, ~5 us per wave at the end of a kernel).
+template <int N> SR_DEV void half_sum32_step(float (&v)[32], int r) {
+  const bool up = (r & N) != 0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const float keep = up ? v[j + N] : v[j], send = up ? v[j] : v[j + N];
+    v[j] = keep + __shfl_xor(send, N);
+  }
+}
+SR_DEV float half_sum32(const float (&a)[16], const float (&b)[16], int r) {
+  float v[32];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { v[i] = a[i]; v[16 + i] = b[i]; }
+  half_sum32_step<16>(v, r);
+  half_sum32_step<8>(v, r);
+  half_sum32_step<4>(v, r);
+  half_sum32_step<2>(v, r);
+  half_sum32_step<1>(v, r);
+  return v[0];
+}
+
 // accumulator tile -> [reg i][lane] floats of a slab (LDS or global), plain stores.  LDS float atomics
 // (ds_add_f32) measured ~1500 cycles per wave-instruction on gfx950: never reduce through them.
 SR_DEV void slab_store_tile(float* slab, int tile, const f32x16& acc, int lane) {
