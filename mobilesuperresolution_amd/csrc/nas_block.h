@@ -634,3 +634,107 @@ __global__ __launch_bounds__(768) void nas_dw_wgrad_kernel(const T* __restrict__
   else if (blockIdx.y == 1) nas_dw_wgrad_k<T, F, 1>(X1, GT, yin, GZ + vstride, dwp, out, N, H, W, tiles_x, tiles_per_img);
   else nas_dw_wgrad_k<T, F, 2>(X1, GT, yin, GZ + 2 * vstride, dwp, out, N, H, W, tiles_x, tiles_per_img);
 }
+
+// The three stencils from ONE workgroup per tile (bf16; in fp32 the four staged images do not fit the LDS): x1 is staged
+// once instead of three times, the 83 taps fill 7 accumulator tiles on each of 12 waves (83 / 84 slots used, against
+// 9 / 12 + 25 / 36 + 49 / 60 over three workgroups that could not share a CU for their registers), and the staging loads
+// are issued in batches.  Wave w owns the taps w, w + 12, ... of the concatenated tap list 3x3 | 5x5 | 7x7 (the slab's own
+// order); the GZ_k fragment is reloaded only where consecutive slots change stencil.  grid = (wgs).
+template <int F>
+__global__ __launch_bounds__(768) void nas_dw_wgrad3_kernel(const __bf16* __restrict__ yin, const __bf16* __restrict__ GZ,
+                                                            const float* __restrict__ dwp, float* __restrict__ partial,
+                                                            int N, int H, int W, int tiles_x, int tiles_per_img, long vstride) {
+  typedef __bf16 T;
+  typedef NasCfg<F> C;
+  typedef typename FragOf<T>::type FragT;
+  constexpr int NTHREADS = 768, X_ELEMS = (C::NP3 + 2) * 32, NSLOT = 7, NTAP = 83;
+  __shared__ __attribute__((aligned(16))) T smem[X_ELEMS + 3 * C::VT_ELEMS];
+  T* const X1 = smem;                      // m1 * yin with a 3-pixel halo, [NP3 + 2][32] (channels >= F zero)
+  T* const GT = smem + X_ELEMS;            // core tiles of GZ_0..2, [3][NPXC + 1][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31;
+  SR_STAMP_DECL;
+  SR_STAMP();
+  f32x16 acc[NSLOT];
+  int xoff[NSLOT], goff[NSLOT];            // wave-uniform: X1 element offset of the tap, GT element offset of its stencil
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i) {
+    acc[i] = zero16();
+    const int tp = wave + 12 * i;
+    const int k = tp < 9 ? 0 : (tp < 34 ? 1 : 2), lt = tp - (k == 0 ? 0 : (k == 1 ? 9 : 34)), ks = 3 + 2 * k, off = 3 - ks / 2;
+    const int ty = lt / ks, tx = lt - ty * ks;
+    xoff[i] = __builtin_amdgcn_readfirstlane(((off + ty) * C::PW + off + tx) * 32);
+    goff[i] = __builtin_amdgcn_readfirstlane(k * C::VT_ELEMS);
+  }
+  for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
+    const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
+    const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+    const size_t img = (size_t)n * H * W * F;
+    __syncthreads();
+    {
+      constexpr int TOTAL = (C::NP3 + 2) * 4, IT = (TOTAL + NTHREADS - 1) / NTHREADS;
+      FragT f[IT];
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * NTHREADS, hp = idx >> 2, c = idx & 3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[it][j] = (T)0.f;
+        if (hp < C::NP3 && c < C::FC) {
+          const int hy = hp / C::PW, hx = hp - hy * C::PW;
+          const int Y = ty0 - 3 + hy, X = tx0 - 3 + hx;
+          if (Y >= 0 && Y < H && X >= 0 && X < W) f[it] = *reinterpret_cast<const FragT*>(yin + img + ((size_t)Y * W + X) * F + c * 8);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * NTHREADS, c = idx & 3;
+        if (idx < TOTAL) {
+          FragT v = f[it];
+          if (c < C::FC) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (T)((float)v[j] * dwp[C::M1 + c * 8 + j]);
+          }
+          *reinterpret_cast<FragT*>(X1 + idx * 8) = v;
+        }
+      }
+    }
+    nas_stage_vt3<T, C, NTHREADS>(GT, GZ + img, vstride, H, W, ty0, tx0, tid);
+    __syncthreads();
+    SR_STAMP();
+#pragma unroll 1
+    for (int ot = 0; ot < C::NPT_O; ++ot) {
+      const int toy = (ot / (C::TW / 8)) * 4, tox = (ot % (C::TW / 8)) * 8;
+      const int gbase = (toy * C::TW + tox) * 32, xbase = (toy * C::PW + tox) * 32;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        FragT a;
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+          if (wave + 12 * i < NTAP) {
+            if (i == 0 || goff[i] != goff[i - 1]) {
+              const T* g = GT + goff[i] + gbase;
+              a = tr_frag<T>(g, s, lane, [](int p) { return ((p >> 3) * C::TW + (p & 7)) * 32; });
+            }
+            const T* x = X1 + xoff[i] + xbase;
+            acc[i] = mma16<T>(a, tr_frag<T>(x, s, lane, [](int p) { return ((p >> 3) * C::PW + (p & 7)) * 32; }), acc[i]);
+          }
+        }
+      }
+    }
+    SR_STAMP();
+  }
+  // diagonal of every tile: accumulator register q of lane (r, hh) is row (q & 3) + 8 (q >> 2) + 4 hh, column r
+  float* out = partial + (size_t)blockIdx.x * C::DWB_SLAB;
+  const bool mine = (lane >> 5) == ((r >> 2) & 1);
+  const int isel = (r & 3) + 4 * (r >> 3);
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i) {
+    const int tp = wave + 12 * i;
+    if (tp < NTAP) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v = (q == isel) ? acc[i][q] : v;
+      if (mine) out[tp * 32 + r] = v;
+    }
+  }
+  SR_STAMP();
+}

@@ -696,6 +696,15 @@ extern "C" int sr_nas_dw_wgrad(const void* yin, const void* GZ, const float* dwp
   if (!yin || !GZ || !dwp || !partial || wgs <= 0 || N <= 0 || H <= 0 || W <= 0) return -2;
   hipStream_t st = (hipStream_t)stream;
   const long vs = (long)N * H * W * F;
+  static const bool wgrad_split = getenv("SR_NAS_WGRAD_SPLIT") != nullptr;
+  if (dtype == SR_DTYPE_BF16 && !wgrad_split && (F == 24 || F == 32)) {   // the three stencils from one workgroup per tile
+    typedef NasCfg<24> C;
+    const int tx = (W + C::TW - 1) / C::TW, tpi = tx * ((H + C::TH - 1) / C::TH);
+    if (F == 24) hipLaunchKernelGGL((nas_dw_wgrad3_kernel<24>), dim3(wgs), dim3(768), 0, st, (const __bf16*)yin, (const __bf16*)GZ, dwp, partial, N, H, W, tx, tpi, vs);
+    else hipLaunchKernelGGL((nas_dw_wgrad3_kernel<32>), dim3(wgs), dim3(768), 0, st, (const __bf16*)yin, (const __bf16*)GZ, dwp, partial, N, H, W, tx, tpi, vs);
+    SR_HIP_CHECK_LAUNCH();
+    return 0;
+  }
 #define CALL(T, F_) { typedef NasCfg<F_> C; const int tx = (W + C::TW - 1) / C::TW, tpi = tx * ((H + C::TH - 1) / C::TH); \
     hipLaunchKernelGGL((nas_dw_wgrad_kernel<T, F_>), dim3(wgs, 3), dim3(768), 0, st, (const T*)yin, (const T*)GZ, dwp, partial, N, H, W, tx, tpi, vs); }
   SR_NAS_DISPATCH(CALL)
