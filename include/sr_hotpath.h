@@ -250,6 +250,19 @@ int sr_nas_body_bwd(const void* ys, const void* V, const void* g_out, void* g_tm
                     long scal_bs, float* part_pw, long pw_bs, float* part_dw, long dw_bs, int wgs, int nb, int N, int H, int W,
                     int F, int dtype, void** g_in, sr_stream_t stream);
 
+/* Parameter plumbing of a table-described model (the supernet body; the same kernels sr_wdsr_net_forward / _backward run on
+ * BASIC_MODEL's tables): weight-norm of the flat fp32 parameters into `src` (reference: torch.nn.utils.weight_norm around
+ * every conv, models/wdsr_b.py:375-402), then up to four gathers of `src` into the packed operand tables the compute
+ * kernels read; and the way back: workgroup slabs summed and scattered into `dsrc` (laid out like `src`, plus whatever extra
+ * columns the tables name), then the weight-norm backward into `gflat` (laid out like `flat`; entries no table row names are
+ * left untouched).  chan_tab: int[n_chan][4] = {v_off, g_off, K, dst_off}; bias_tab: int[n_bias][3] = {src_a, src_b | -1, dst}. */
+typedef struct { const int* idx; void* out; long src_off, src_stride; int n, reps, as_float; } sr_pack_seg_t;
+typedef struct { const float* partial; const int* sidx; const int* dst; long dst_off, dst_stride, slab; int wgs, n, reps; } sr_unpack_seg_t;
+int sr_param_pack(const float* flat, float* src, const int* chan_tab, int n_chan, const int* bias_tab, const float* bias_const,
+                  int n_bias, const sr_pack_seg_t* segs, int nseg, int dtype, sr_stream_t stream);
+int sr_param_grads(const float* flat, float* dsrc, float* gflat, const int* chan_tab, int n_chan, const int* bias_tab,
+                   int n_bias, const sr_unpack_seg_t* segs, int nseg, sr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Whole-network entry points: everything BASIC_MODEL.forward (models/basic_wdsr_b.py:85-93) and its
  * autograd backward do, as ONE call each.  The caller (mobilesuperresolution_amd/models) owns every

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SR_HOTPATH_LIB_PATH (tools/ only): an explicitly named build of the same sources (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("SR_HOTPATH_LIB_PATH") or os.path.join(
     _HERE, "libsr_hotpath_dbg.so" if os.environ.get("SR_HOTPATH_DEBUG_LIB") == "1" else "libsr_hotpath.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
 
 _P, _I, _Z, _L, _F = c_void_p, c_int, c_size_t, ctypes.c_long, ctypes.c_float
@@ -53,6 +53,8 @@ SIGNATURES = {
     "sr_nas_pw_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_nas_dw_bwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_patch_gather": ([_P, _P, _P, _P, _I, _I, _I, _P], _I),
+    "sr_param_pack": ([_P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P], _I),
+    "sr_param_grads": ([_P, _P, _P, _P, _I, _P, _I, _P, _I, _P], _I),
     "sr_nas_body_fwd": ([_P, _P, _P, _L, _P, _L, _P, _L, _P, _L] + [_I] * 6 + [_P], _I),
     "sr_nas_body_bwd": ([_P] * 7 + [_L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L] + [_I] * 7 + [_P, _P], _I),
     "sr_psnr": ([_P, _P, _P, _P] + [_I] * 7 + [_P], _I),
@@ -98,6 +100,17 @@ class C3Warp(ctypes.Structure):
 class C3Unpack(ctypes.Structure):
     """mirror of sr_c3_unpack_t"""
     _fields_ = [("sidx0", _P), ("dst0", _P), ("n0", _I), ("sidx1", _P), ("dst1", _P), ("n1", _I), ("gflat", _P)]
+
+
+class PackSeg(ctypes.Structure):
+    """mirror of sr_pack_seg_t"""
+    _fields_ = [("idx", _P), ("out", _P), ("src_off", _L), ("src_stride", _L), ("n", _I), ("reps", _I), ("as_float", _I)]
+
+
+class UnpackSeg(ctypes.Structure):
+    """mirror of sr_unpack_seg_t"""
+    _fields_ = [("partial", _P), ("sidx", _P), ("dst", _P), ("dst_off", _L), ("dst_stride", _L), ("slab", _L), ("wgs", _I),
+                ("n", _I), ("reps", _I)]
 
 
 class AdamScalars(ctypes.Structure):

@@ -16,7 +16,7 @@
 #include "train_step.h"
 #include "pixel_shuffle.h"
 
-extern "C" int sr_abi_version(void) { return 6; }
+extern "C" int sr_abi_version(void) { return 7; }
 
 namespace {
 
@@ -938,6 +938,54 @@ extern "C" int sr_wdsr_net_backward_part(const sr_wdsr_net_t* n, int part, sr_st
 }
 
 extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) { return sr_wdsr_net_backward_part(n, 0, stream); }
+
+// table-driven parameter plumbing for callers other than the BASIC_MODEL net struct (the supernet body)
+extern "C" int sr_param_pack(const float* flat, float* src, const int* chan_tab, int n_chan, const int* bias_tab,
+                             const float* bias_const, int n_bias, const sr_pack_seg_t* segs, int nseg, int dtype,
+                             sr_stream_t stream) {
+  if (!flat || !src || !chan_tab || n_chan <= 0 || n_bias < 0 || (n_bias > 0 && (!bias_tab || !bias_const)) || !segs || nseg < 1 ||
+      nseg > 4 || (dtype != SR_DTYPE_F32 && dtype != SR_DTYPE_BF16))
+    return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const int cb = (n_chan + 3) / 4, bb = (n_bias + 255) / 256;
+  hipLaunchKernelGGL(wn_src_kernel, dim3(cb + bb), dim3(256), 0, st, flat, src, (const int4*)chan_tab, n_chan, bias_tab, bias_const,
+                     n_bias, cb);
+  PackSegs ps;
+  ps.nseg = nseg;
+  int blk = 0;
+  for (int k = 0; k < nseg; ++k) {
+    const sr_pack_seg_t& g = segs[k];
+    if (!g.idx || !g.out || g.n <= 0 || g.reps <= 0) return -2;
+    ps.s[k] = PackSeg{g.idx, g.out, g.src_off, g.src_stride, g.n, g.reps, g.as_float, blk};
+    blk += g.reps * ((g.n + 255) / 256);
+  }
+  if (dtype == SR_DTYPE_BF16) hipLaunchKernelGGL((pack_all_kernel<__bf16>), dim3(blk), dim3(256), 0, st, src, ps);
+  else hipLaunchKernelGGL((pack_all_kernel<float>), dim3(blk), dim3(256), 0, st, src, ps);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sr_param_grads(const float* flat, float* dsrc, float* gflat, const int* chan_tab, int n_chan, const int* bias_tab,
+                              int n_bias, const sr_unpack_seg_t* segs, int nseg, sr_stream_t stream) {
+  if (!flat || !dsrc || !gflat || !chan_tab || n_chan <= 0 || n_bias < 0 || (n_bias > 0 && !bias_tab) || !segs || nseg < 1 || nseg > 4)
+    return -2;
+  hipStream_t st = (hipStream_t)stream;
+  UnpackSegs us;
+  us.nseg = nseg;
+  int blk = 0;
+  for (int k = 0; k < nseg; ++k) {
+    const sr_unpack_seg_t& g = segs[k];
+    if (!g.partial || !g.sidx || !g.dst || g.n <= 0 || g.reps <= 0 || g.wgs <= 0) return -2;
+    us.s[k] = UnpackSeg{g.partial, g.sidx, g.dst, g.dst_off, g.dst_stride, g.slab, g.wgs, g.n, g.reps, blk};
+    blk += g.reps * ((g.n + 63) / 64);
+  }
+  hipLaunchKernelGGL(unpack_all_kernel, dim3(blk), dim3(64 * UNPACK_Q), 0, st, dsrc, us);
+  const int cb = (n_chan + 3) / 4, bb = (n_bias + 255) / 256;
+  hipLaunchKernelGGL(wn_bwd_kernel, dim3(cb + bb), dim3(256), 0, st, flat, dsrc, gflat, (const int4*)chan_tab, n_chan, bias_tab,
+                     n_bias, cb);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
 
 // every block of the supernet body from one call each way
 extern "C" int sr_nas_body_fwd(void* ys, void* V, const float* dwp, long dwp_bs, const void* frags, long frags_bs, const float* tabs,

@@ -18,9 +18,12 @@ def rounding(weight: torch.Tensor, least_channel: int = 8) -> torch.Tensor:
     least_channel = 0 disables the fallback (reference models/ops.py:33-43)."""
     w = (weight >= 0.5).float()
     if least_channel > 0:
-        v, _ = torch.topk(weight, least_channel, dim=0)
-        # same selection as the reference's `if torch.sum(w) >= least_channel`, without the host sync it implies
-        return torch.where(torch.sum(w) >= least_channel, w, (weight >= v[-1]).float())
+        # w >= k-th largest  <=>  fewer than k entries are strictly larger (ties at the k-th value all stay): two small
+        # launches instead of topk's select + sort; and the same selection as the reference's `if torch.sum(w) >=
+        # least_channel`, without the host sync it implies
+        flat = weight.reshape(-1)
+        topk = ((flat.unsqueeze(0) > flat.unsqueeze(1)).sum(1) < least_channel).float().view_as(weight)
+        return torch.where(torch.sum(w) >= least_channel, w, topk)
     return w
 
 
@@ -39,10 +42,12 @@ class BinaryConv2d(nn.Module):
     def init(self, value=0.5):
         init.constant_(self.weight, value)
 
-    def effective(self) -> torch.Tensor:
-        """(C,) tensor: value = 0/1 mask, gradient = identity to `weight` (models/ops.py:18-24)."""
+    def effective(self, mask: torch.Tensor = None) -> torch.Tensor:
+        """(C,) tensor: value = 0/1 mask, gradient = identity to `weight` (models/ops.py:18-24).  `mask`: rounding(weight)
+        if the caller already has it."""
         w = self.weight.detach()
-        mask = rounding(w, self.least_channel)
+        if mask is None:
+            mask = rounding(w, self.least_channel)
         return (self.weight - (w - mask)).reshape(-1)
 
     def forward(self, x, y=None):

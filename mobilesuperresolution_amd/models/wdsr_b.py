@@ -240,6 +240,117 @@ class _NasBodyFunction(torch.autograd.Function):
         return g, g_wdw[0], g_wdw[1], g_wdw[2], g_bdw, g_wpw, g_bpw, g_mg, g_ms, g_p, g_beta
 
 
+_PREP_CACHE = {}
+
+
+def _nas_prep_dev_tables(Fch: int, nb: int, layout, device_index: int):
+    """packing.nas_prep_tables on the device + the constant columns of a source buffer (cached per geometry and device)"""
+    key = (Fch, nb, layout, device_index)
+    t = _PREP_CACHE.get(key)
+    if t is None:
+        h = P.nas_prep_tables(Fch, nb, layout)
+        base = P.nas_tables(Fch)
+        dev = torch.device("cuda", device_index)
+        t = {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in h.items()}
+        for k in ("dwp", "frags", "tabs"):
+            t[k] = torch.from_numpy(np.ascontiguousarray(base[k], dtype=np.int32)).to(dev)
+        t["bias_const"] = torch.zeros(h["bias_tab"].shape[0], dtype=torch.float32, device=dev)
+        t["pw_slab"], t["dw_slab"] = base["pw_slab"], base["dw_slab"]
+        _PREP_CACHE[key] = t
+    return t
+
+
+class _NasBodyNative(torch.autograd.Function):
+    """_NasBodyFunction with the parameter plumbing native as well: weight-norm of the six convs of every block, the
+    gathers into the kernels' operand tables, and on the way back the slab sums, the scatter into d(source) and the
+    weight-norm backward straight into a gradient laid out like the flat parameter -- two launches each way
+    (sr_param_pack / sr_param_grads, the kernels BASIC_MODEL's net calls use) instead of ~70 small torch launches.
+    Inputs: flat (the body parameter), mg (F,), MS (nb, F), P (nb, 3), BETA (nb, 2), layout / frozen of the model."""
+
+    @staticmethod
+    def forward(ctx, y0, flat, mg, MS, P_, BETA, layout, frozen):
+        n, h, w, f = y0.shape
+        nb = MS.shape[0]
+        dev, dt = y0.device, y0.dtype
+        tb = _nas_prep_dev_tables(f, nb, layout, dev.index if dev.index is not None else torch.cuda.current_device())
+        o, size = tb["off"], tb["size"]
+        mgf, MSf = mg.detach().float(), MS.detach().float()
+        flatd = flat.detach()
+        src = torch.empty((nb, size), dtype=torch.float32, device=dev)
+        src[:, o["mg"]:o["zero"]] = torch.cat([mgf.reshape(1, f).expand(nb, f), MSf, mgf.reshape(1, f) * MSf], dim=1)
+        src[:, o["zero"]:] = _const(dev, (0.0, 1.0))
+        code = L.DTYPE_CODE[dt]
+        dwp = torch.empty((nb, tb["dwp"].numel()), dtype=torch.float32, device=dev)
+        frags = torch.empty((nb, tb["frags"].numel()), dtype=dt, device=dev)
+        tabs = torch.empty((nb, tb["tabs"].numel()), dtype=torch.float32, device=dev)
+        segs = (L.PackSeg * 3)(L.PackSeg(tb["dwp"].data_ptr(), dwp.data_ptr(), 0, size, dwp.shape[1], nb, 1),
+                               L.PackSeg(tb["frags"].data_ptr(), frags.data_ptr(), 0, size, frags.shape[1], nb, 0),
+                               L.PackSeg(tb["tabs"].data_ptr(), tabs.data_ptr(), 0, size, tabs.shape[1], nb, 1))
+        L.launch("sr_param_pack", L.lib().sr_param_pack, flatd.data_ptr(), src.data_ptr(), tb["chan_tab"].data_ptr(),
+                 tb["chan_tab"].shape[0], tb["bias_tab"].data_ptr(), tb["bias_const"].data_ptr(), tb["bias_tab"].shape[0], segs, 3,
+                 code, L.stream_ptr())
+        scal = torch.cat([P_.detach().float(), BETA.detach().float()[:, 1:2]], dim=1).contiguous()
+        ys = torch.empty((nb + 1, n, h, w, f), dtype=dt, device=dev)
+        ys[0] = y0
+        V = torch.empty((nb, 3, n, h, w, f), dtype=dt, device=dev)
+        L.launch("sr_nas_body_fwd", L.lib().sr_nas_body_fwd, ys.data_ptr(), V.data_ptr(), dwp.data_ptr(),
+                 dwp.stride(0) * dwp.element_size(), frags.data_ptr(), frags.stride(0) * frags.element_size(), tabs.data_ptr(),
+                 tabs.stride(0) * tabs.element_size(), scal.data_ptr(), scal.stride(0) * scal.element_size(), nb, n, h, w, f, code,
+                 L.stream_ptr())
+        ctx.layout, ctx.frozen = layout, frozen
+        # the parameter values the weight-norm backward needs are the ones of THIS forward: keep a snapshot only if the
+        # caller may write the parameter in place before backward (forward() itself rewrites beta1 / beta2, which no table names)
+        ctx.save_for_backward(ys, V, dwp, frags, tabs, scal, MSf, P_.detach().float(), BETA.detach().float(), flat)
+        return ys[nb]
+
+    @staticmethod
+    def backward(ctx, gy):
+        ys, V, dwp, frags, tabs, scal, MS, P_, BETA, flat = ctx.saved_tensors
+        nb, n, h, w, f = V.shape[0], V.shape[2], V.shape[3], V.shape[4], V.shape[5]
+        dev, dt = ys.device, ys.dtype
+        tb = _nas_prep_dev_tables(f, nb, ctx.layout, dev.index if dev.index is not None else torch.cuda.current_device())
+        code = L.DTYPE_CODE[dt]
+        wgs = int(os.environ.get("SR_NAS_WGS", 256))
+        GZ = torch.empty_like(V[0])
+        part_pw = torch.empty((nb, wgs, tb["pw_slab"]), dtype=torch.float32, device=dev)
+        part_dw = torch.empty((nb, wgs, tb["dw_slab"]), dtype=torch.float32, device=dev)
+        g = gy.contiguous()
+        gbuf = [torch.empty_like(g), torch.empty_like(g)]
+        import ctypes
+        g_in = ctypes.c_void_p()
+        L.launch("sr_nas_body_bwd", L.lib().sr_nas_body_bwd, ys.data_ptr(), V.data_ptr(), g.data_ptr(), gbuf[0].data_ptr(),
+                 gbuf[1].data_ptr(), GZ.data_ptr(), dwp.data_ptr(), dwp.stride(0) * dwp.element_size(), frags.data_ptr(),
+                 frags.stride(0) * frags.element_size(), tabs.data_ptr(), tabs.stride(0) * tabs.element_size(), scal.data_ptr(),
+                 scal.stride(0) * scal.element_size(), part_pw.data_ptr(), part_pw.stride(0) * 4, part_dw.data_ptr(),
+                 part_dw.stride(0) * 4, wgs, nb, n, h, w, f, code, ctypes.byref(g_in), L.stream_ptr())
+        g = gbuf[0] if g_in.value == gbuf[0].data_ptr() else gbuf[1]
+        ds, ex = tb["ds"], tb["extra"]
+        dsrc = torch.empty((nb, ds), dtype=torch.float32, device=dev)
+        gflat = torch.zeros_like(flat)
+        flatd = flat.detach()
+        segs = (L.UnpackSeg * 2)(
+            L.UnpackSeg(part_pw.data_ptr(), tb["pw_sidx"].data_ptr(), tb["pw_dst"].data_ptr(), 0, ds, tb["pw_slab"], wgs,
+                        tb["pw_sidx"].numel(), nb),
+            L.UnpackSeg(part_dw.data_ptr(), tb["dw_sidx"].data_ptr(), tb["dw_dst"].data_ptr(), 0, ds, tb["dw_slab"], wgs,
+                        tb["dw_sidx"].numel(), nb))
+        L.launch("sr_param_grads", L.lib().sr_param_grads, flatd.data_ptr(), dsrc.data_ptr(), gflat.data_ptr(),
+                 tb["chan_bwd"].data_ptr(), tb["chan_bwd"].shape[0], tb["bias_bwd"].data_ptr(), tb["bias_bwd"].shape[0], segs, 2,
+                 L.stream_ptr())
+        for name, o_, n_, _shape in ctx.layout:                                        # kernel_grad(False) & co: frozen kinds
+            if name in ctx.frozen and name.startswith("body."):
+                gflat[o_:o_ + n_].zero_()
+        r = dsrc[:, ex["r"]:ex["r"] + 3 * f].view(nb, 3, f)                            # r_k[c] = sum gy[c] relu(u_k)[c]
+        sxy = dsrc[:, ex["sxy"]]
+        sA, sB = dsrc[:, ex["sA"]:ex["sA"] + f], dsrc[:, ex["sB"]:ex["sB"] + f]
+        b2 = BETA[:, 1]
+        q = (r * MS.view(nb, 1, f)).sum(2)                                             # q_k = sum_c ms[c] r_k[c]
+        g_p = b2.view(nb, 1) * q
+        g_beta = torch.stack([sxy, sxy + (P_ * q).sum(1)], dim=1)
+        g_ms = sA + b2.view(nb, 1) * (P_.view(nb, 3, 1) * r).sum(1)
+        g_mg = sB.sum(0)
+        return g, gflat, g_mg, g_ms, g_p, g_beta, None, None
+
+
 class _GateFunction(torch.autograd.Function):
     """ConditionFunction over all blocks at once: (1,0) where alpha1 >= alpha2 else (0,1); straight-through."""
 
@@ -428,11 +539,13 @@ def _body_kinds(f: int):
 class _SplitFlat(torch.autograd.Function):
     """flat body parameter -> one (nb, ...) tensor per kind.  Forward is ONE copy (the kinds are slices of it: later in-place
     writes into the parameter -- forward() rewrites beta1 / beta2 like the reference, :534 -- cannot disturb what autograd
-    saved); backward is ONE cat.  `frozen`: kinds whose gradient is zeroed (length_grad / mask_grad / kernel_grad(False))."""
+    saved); backward is one fill plus a copy per kind that received a gradient (with the native plumbing of the convs
+    that is the four mask / gate kinds).  `frozen`: kinds whose gradient is zeroed (length_grad / mask_grad / kernel_grad(False))."""
 
     @staticmethod
     def forward(ctx, flat, layout, frozen):
         ctx.layout, ctx.frozen = layout, frozen
+        ctx.set_materialize_grads(False)               # kinds nothing used arrive as None, not as 20-odd zero fills
         snap = flat.detach().clone()
         outs = tuple(snap[o:o + n].view(shape) for (_, o, n, shape) in layout)
         ctx.mark_non_differentiable(*[t for t, (name, *_r) in zip(outs, layout) if name in frozen])
@@ -440,17 +553,15 @@ class _SplitFlat(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        dev = next(g.device for g in grads if g is not None)
-        zeros = {}
-        parts = []
+        dev = next((g.device for g in grads if g is not None), None)
+        if dev is None:
+            return None, None, None
+        total = ctx.layout[-1][1] + ctx.layout[-1][2]
+        out = torch.zeros(total, dtype=torch.float32, device=dev)          # one fill, then only the kinds that have a gradient
         for g, (name, o, n, shape) in zip(grads, ctx.layout):
-            if g is None or name in ctx.frozen:
-                if n not in zeros:
-                    zeros[n] = torch.zeros(n, dtype=torch.float32, device=dev)
-                parts.append(zeros[n])
-            else:
-                parts.append(g.reshape(-1))
-        return torch.cat(parts), None, None
+            if g is not None and name not in ctx.frozen:
+                out[o:o + n] = g.reshape(-1)
+        return out, None, None
 
 
 class _Holder:
@@ -652,8 +763,9 @@ class NAS_MODEL(nn.Module):
         x = x.contiguous().float()
         f, dt = self.num_residual_units, self.hot_dtype
         y = _HeadFunction.apply(x, self.head.weight(), self.head.bias, f, dt, self.image_mean)
-        mg = self.mask.effective()
-        y, speed_accu = self._body(y, mg)
+        mask_hard = rounding(self.mask.weight.detach(), self.mask.least_channel)   # once: the mask's value and the latency head's count
+        mg = self.mask.effective(mask_hard)
+        y, speed_accu = self._body(y, mg, mask_hard)
         y = (y.float() * mg.view(1, 1, 1, -1)).to(dt)                         # y = self.mask(y) before the tail (:118-119)
         btot = self.tail.bias + self.skip.bias + self.image_mean
         out = _TailFunction.apply(y, x, self.tail.weight(), self.skip.weight(), btot, self.scale, self.image_mean)
@@ -667,7 +779,7 @@ class NAS_MODEL(nn.Module):
             self._skip_key = key
         return self._skip_val
 
-    def _body(self, y, mg):
+    def _body(self, y, mg, mask_hard=None):
         """All MyAggregationLayer blocks (reference wdsr_b.py:111-117 with :517-546 per block) through ONE autograd node:
         weight-norm, masks, gates, softmax and the latency terms are a few batched ops over the stacked kinds.
         Returns (y NHWC, speed_accu (1,))."""
@@ -678,11 +790,11 @@ class NAS_MODEL(nn.Module):
         idx = [i for i in range(nball) if not (skipped and skipped[i])]   # eval: a skipped block only applies the (idempotent 0/1) global mask
         # latency head, reference speed_estimator.py:57-76 (raw alpha, rounding() with its default least_channel = 8)
         with torch.no_grad():
-            c_mask = rounding(self.mask.weight.detach()).sum()
+            c_mask = (rounding(self.mask.weight.detach()) if mask_hard is None or self.mask.least_channel != 8 else mask_hard).sum()
             W = K["split.weight"].detach().view(nball, -1)                                           # (NB, F)
-            kth = torch.topk(W, 8, dim=1).values[:, -1:]
             hard = (W >= 0.5).float()
-            c_split = torch.where(hard.sum(1, keepdim=True) >= 8, hard, (W >= kth).float()).sum(1)
+            top8 = ((W.unsqueeze(1) > W.unsqueeze(2)).sum(2) < 8).float()      # W >= 8th largest of its row (ties kept), as rounding()
+            c_split = torch.where(hard.sum(1, keepdim=True) >= 8, hard, top8).sum(1)
             A = K["alpha"].detach()                                                                  # (NB, 3)
             speed_curr = ((c_split + 0.2 * c_mask).view(-1, 1) * _const(dev, (9.0, 25.0, 49.0)).view(1, 3) * A / 40).sum(1)
         if self.training:
@@ -701,13 +813,6 @@ class NAS_MODEL(nn.Module):
             it = torch.tensor(idx, device=dev)
             K = {k: v.index_select(0, it) for k, v in K.items()}
 
-        def wn(k, j):                                # weight-normalised conv j (0 depthwise, 2 pointwise) of branch k
-            v, g = K[f"body.{k}.0.body.{j}.weight_v"], K[f"body.{k}.0.body.{j}.weight_g"]
-            return torch._weight_norm(v.reshape(nbk * f, *v.shape[2:]), g.reshape(nbk * f, 1, 1, 1), 0).view(v.shape)
-        WDW = [wn(k, 0) for k in (3, 5, 7)]
-        WPW = torch.stack([wn(k, 2) for k in (3, 5, 7)], dim=1)                                      # (nb, 3, F, F, 1, 1)
-        BDW = torch.stack([K[f"body.{k}.0.body.0.bias"] for k in (3, 5, 7)], dim=1)                  # (nb, 3, F)
-        BPW = torch.stack([K[f"body.{k}.0.body.2.bias"] for k in (3, 5, 7)], dim=1)
         SW = K["split.weight"].view(nbk, -1)                                                         # (nb, F)
         SWd = SW.detach()
         MS = SW - (SWd - (SWd >= 0.5).float())                   # BinaryConv2d(least_channel=0): value 0/1, gradient 1
@@ -716,6 +821,17 @@ class NAS_MODEL(nn.Module):
             BETA = gates
         else:
             BETA = _const(dev, (0.0, 1.0)).view(1, 2).expand(nbk, 2)
+        if nbk == nball and not os.environ.get("SR_NAS_TORCH_PREP"):
+            # every block runs: weight-norm / packing / gradient gathers native too (two launches each way)
+            return _NasBodyNative.apply(y, self.flat, mg, MS, P, BETA, self._layout, self._frozen), speed_accu
+
+        def wn(k, j):                                # weight-normalised conv j (0 depthwise, 2 pointwise) of branch k
+            v, g = K[f"body.{k}.0.body.{j}.weight_v"], K[f"body.{k}.0.body.{j}.weight_g"]
+            return torch._weight_norm(v.reshape(nbk * f, *v.shape[2:]), g.reshape(nbk * f, 1, 1, 1), 0).view(v.shape)
+        WDW = [wn(k, 0) for k in (3, 5, 7)]
+        WPW = torch.stack([wn(k, 2) for k in (3, 5, 7)], dim=1)                                      # (nb, 3, F, F, 1, 1)
+        BDW = torch.stack([K[f"body.{k}.0.body.0.bias"] for k in (3, 5, 7)], dim=1)                  # (nb, 3, F)
+        BPW = torch.stack([K[f"body.{k}.0.body.2.bias"] for k in (3, 5, 7)], dim=1)
         y = _NasBodyFunction.apply(y, WDW[0], WDW[1], WDW[2], BDW, WPW, BPW, mg, MS, P, BETA)
         return y, speed_accu
 

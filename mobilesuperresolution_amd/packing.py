@@ -482,3 +482,46 @@ def nas_tables(F: int):
     g_bdw = np.stack([(83 + k) * 32 + np.arange(F) for k in range(3)]).reshape(-1)
     return dict(off=o, dwp=dwp, frags=frags, tabs=tabs, g_wpw=g_wpw, g_bpw=g_bpw, g_r=g_r, g_wdw=g_wdw, g_bdw=g_bdw,
                 g_sA=86 * 32 + np.arange(F), g_sB=87 * 32 + np.arange(F), pw_slab=3 * 1088 + 4, dw_slab=88 * 32, sxy=3 * 1088)
+
+
+def nas_prep_tables(F: int, nb: int, layout):
+    """Tables for the native parameter plumbing of the supernet body (csrc/wdsr_prep.h through sr_param_pack / sr_param_grads).
+    `layout`: NAS_MODEL._layout = (key suffix, offset in the flat parameter, count, (nb, ...) shape) per kind, stacked over
+    blocks.  Source row of block b = nas_tables(F)['off'] columns; gradient row = the same columns followed by the extra sums
+    r[3][F] | sxy | sA[F] | sB[F] the mask / gate gradients are made of.
+    Returns chan_tab int32[nb * 6F][4] = {v_off, g_off, K, dst}, bias_tab int32[nb * 6F][3] = {flat index, -1, dst},
+    the two slab scatters (sidx, dst) and the row sizes."""
+    t = nas_tables(F)
+    o = t["off"]
+    size = o["size"]
+    lay = {name: (off, n, shape) for name, off, n, shape in layout}
+    ex = dict(r=size, sxy=size + 3 * F, sA=size + 3 * F + 1, sB=size + 4 * F + 1)
+    ds = size + 5 * F + 1
+    chan, bias = [], []
+    c = np.arange(F)
+    for b in range(nb):
+        for ki, k in enumerate((3, 5, 7)):
+            for j, (K, dst0) in ((0, (k * k, o[f"wdw{k}"])), (2, (F, o["wpw"] + ki * F * F))):
+                ov, _n, _s = lay[f"body.{k}.0.body.{j}.weight_v"]
+                og, _n, _s = lay[f"body.{k}.0.body.{j}.weight_g"]
+                chan.append(np.stack([ov + (b * F + c) * K, og + b * F + c, np.full(F, K), b * size + dst0 + c * K], axis=1))
+                ob, _n, _s = lay[f"body.{k}.0.body.{j}.bias"]
+                bias.append(np.stack([ob + b * F + c, np.full(F, -1), b * size + o["bdw" if j == 0 else "bpw"] + ki * F + c], axis=1))
+    chan_tab = np.concatenate(chan).astype(np.int32)
+    bias_tab = np.concatenate(bias).astype(np.int32)
+    # the weight-norm backward reads d(src) at the same dst offsets but in rows of `ds` columns
+    chan_bwd, bias_bwd = chan_tab.copy(), bias_tab.copy()
+    chan_bwd[:, 3] = (chan_tab[:, 3] // size) * ds + chan_tab[:, 3] % size
+    bias_bwd[:, 2] = (bias_tab[:, 2] // size) * ds + bias_tab[:, 2] % size
+    pw_sidx = np.concatenate([t["g_wpw"], t["g_bpw"], t["g_r"], [t["sxy"]]])
+    pw_dst = np.concatenate([o["wpw"] + np.arange(3 * F * F), o["bpw"] + np.arange(3 * F), ex["r"] + np.arange(3 * F), [ex["sxy"]]])
+    dw_sidx = np.concatenate(list(t["g_wdw"]) + [t["g_bdw"], t["g_sA"], t["g_sB"]])
+    dw_dst = np.concatenate([o["wdw3"] + np.arange(9 * F), o["wdw5"] + np.arange(25 * F), o["wdw7"] + np.arange(49 * F),
+                             o["bdw"] + np.arange(3 * F), ex["sA"] + np.arange(F), ex["sB"] + np.arange(F)])
+    # pairs in slab order: neighbouring threads of the scatter kernel then read neighbouring slab entries
+    op, od = np.argsort(pw_sidx, kind="stable"), np.argsort(dw_sidx, kind="stable")
+    pw_sidx, pw_dst, dw_sidx, dw_dst = pw_sidx[op], pw_dst[op], dw_sidx[od], dw_dst[od]
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    return dict(chan_tab=chan_tab, bias_tab=bias_tab, chan_bwd=i32(chan_bwd), bias_bwd=i32(bias_bwd), pw_sidx=i32(pw_sidx),
+                pw_dst=i32(pw_dst), dw_sidx=i32(dw_sidx), dw_dst=i32(dw_dst), size=size, ds=ds, extra=ex, off=o)
+
