@@ -738,3 +738,45 @@ __global__ __launch_bounds__(768) void nas_dw_wgrad3_kernel(const __bf16* __rest
   }
   SR_STAMP();
 }
+
+// ---------------------------------------------------------------------------------------------
+// The 0/1 masks, gates and latency terms of a supernet step (reference models/ops.py:33-43 rounding(), wdsr_b.py:517-534
+// ConditionFunction, speed_estimator.py:57-76) for every block from ONE small launch -- as torch ops they are ~30 launches
+// of a few microseconds each on tensors of 32 .. 512 values.  Values only: the straight-through gradients stay with
+// the caller.  rounding(w, 8): w >= 0.5, or -- if fewer than 8 entries pass -- w >= the 8th largest (ties kept), i.e.
+// fewer than 8 entries strictly larger.
+// out: mask_hard[F] | c_mask | ms_hard[nb][F] (split.weight >= 0.5) | c_split[nb] | speed_curr[nb] | gates[nb][2]
+// ---------------------------------------------------------------------------------------------
+SR_DEV float nas_rounding8(const float* __restrict__ w, int F, int i) {
+  int pass = 0, above = 0;
+  const float wi = w[i];
+  for (int j = 0; j < F; ++j) { pass += w[j] >= 0.5f; above += w[j] > wi; }
+  return pass >= 8 ? (wi >= 0.5f ? 1.f : 0.f) : (above < 8 ? 1.f : 0.f);
+}
+
+__global__ __launch_bounds__(256) void nas_scalars_kernel(const float* __restrict__ mask_w, const float* __restrict__ split_w,
+                                                          const float* __restrict__ alpha, const float* __restrict__ alpha1,
+                                                          const float* __restrict__ alpha2, int nb, int F,
+                                                          float* __restrict__ out) {
+  float* const mask_hard = out;
+  float* const c_mask_o = out + F;
+  float* const ms_hard = out + F + 1;
+  float* const c_split_o = ms_hard + (size_t)nb * F;
+  float* const speed = c_split_o + nb;
+  float* const gates = speed + nb;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
+  for (int i = tid; i < F; i += nthr) mask_hard[i] = nas_rounding8(mask_w, F, i);
+  for (int i = tid; i < nb * F; i += nthr) ms_hard[i] = split_w[i] >= 0.5f ? 1.f : 0.f;
+  for (int b = tid; b < nb; b += nthr) {
+    float cm = 0.f, cs = 0.f;
+    for (int i = 0; i < F; ++i) { cm += nas_rounding8(mask_w, F, i); cs += nas_rounding8(split_w + (size_t)b * F, F, i); }
+    if (b == 0) *c_mask_o = cm;
+    c_split_o[b] = cs;
+    const float t = cs + 0.2f * cm;
+    speed[b] = t * 9.f * alpha[3 * b] / 40.f + t * 25.f * alpha[3 * b + 1] / 40.f + t * 49.f * alpha[3 * b + 2] / 40.f;
+    const float g1 = alpha1[b] >= alpha2[b] ? 1.f : 0.f;
+    gates[2 * b] = g1;
+    gates[2 * b + 1] = 1.f - g1;
+  }
+}
+

@@ -987,6 +987,16 @@ extern "C" int sr_param_grads(const float* flat, float* dsrc, float* gflat, cons
   return 0;
 }
 
+extern "C" int sr_nas_scalars(const float* mask_w, const float* split_w, const float* alpha, const float* alpha1,
+                              const float* alpha2, int nb, int F, float* out, sr_stream_t stream) {
+  if (!mask_w || !split_w || !alpha || !alpha1 || !alpha2 || !out || nb <= 0 || F < 8 || F > 1024) return -2;
+  const int blocks = (nb * F + 255) / 256;
+  hipLaunchKernelGGL(nas_scalars_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mask_w, split_w, alpha, alpha1, alpha2, nb,
+                     F, out);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+
 // every block of the supernet body from one call each way
 extern "C" int sr_nas_body_fwd(void* ys, void* V, const float* dwp, long dwp_bs, const void* frags, long frags_bs, const float* tabs,
                                long tabs_bs, const float* scal, long scal_bs, int nb, int N, int H, int W, int F, int dtype,

@@ -364,6 +364,18 @@ class _GateFunction(torch.autograd.Function):
         return g[:, 0], g[:, 1]
 
 
+class _GateValues(torch.autograd.Function):
+    """_GateFunction whose values came from sr_nas_scalars"""
+
+    @staticmethod
+    def forward(ctx, A1, A2, values):
+        return values.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, 0], g[:, 1], None
+
+
 class Split_Block(nn.Module):
     """reference wdsr_b.py:405-501 (block_type 'normal', seperate_type True)"""
 
@@ -763,13 +775,28 @@ class NAS_MODEL(nn.Module):
         x = x.contiguous().float()
         f, dt = self.num_residual_units, self.hot_dtype
         y = _HeadFunction.apply(x, self.head.weight(), self.head.bias, f, dt, self.image_mean)
-        mask_hard = rounding(self.mask.weight.detach(), self.mask.least_channel)   # once: the mask's value and the latency head's count
+        sc = self._scalars() if self.mask.least_channel == 8 and not os.environ.get("SR_NAS_TORCH_PREP") else None
+        # once: the mask's value and the latency head's count
+        mask_hard = sc["mask_hard"] if sc is not None else rounding(self.mask.weight.detach(), self.mask.least_channel)
         mg = self.mask.effective(mask_hard)
-        y, speed_accu = self._body(y, mg, mask_hard)
+        y, speed_accu = self._body(y, mg, mask_hard, sc)
         y = (y.float() * mg.view(1, 1, 1, -1)).to(dt)                         # y = self.mask(y) before the tail (:118-119)
         btot = self.tail.bias + self.skip.bias + self.image_mean
         out = _TailFunction.apply(y, x, self.tail.weight(), self.skip.weight(), btot, self.scale, self.image_mean)
         return out, speed_accu
+
+    def _scalars(self):
+        """0/1 masks, gates and latency terms of this step from one launch (csrc/nas_block.h nas_scalars_kernel): views
+        mask_hard (F,1,1,1), ms_hard (nb, F), speed_curr (nb,), gates (nb, 2) of one buffer"""
+        nb, f = self.num_blocks, self.num_residual_units
+        fl = self.flat.detach()
+        out = torch.empty(f + 1 + nb * (f + 4), dtype=torch.float32, device=fl.device)
+        L.launch("sr_nas_scalars", L.lib().sr_nas_scalars, self.mask.weight.detach().data_ptr(),
+                 self.kind("split.weight", fl).data_ptr(), self.kind("alpha", fl).data_ptr(), self.kind("alpha1", fl).data_ptr(),
+                 self.kind("alpha2", fl).data_ptr(), nb, f, out.data_ptr(), L.stream_ptr())
+        o = f + 1
+        return dict(mask_hard=out[:f].view(f, 1, 1, 1), ms_hard=out[o:o + nb * f].view(nb, f),
+                    speed_curr=out[o + nb * (f + 1):o + nb * (f + 2)], gates=out[o + nb * (f + 2):].view(nb, 2))
 
     def _skip_flags(self):
         """eval-time gates alpha1 >= alpha2 of all blocks as host bools, read back once per parameter version"""
@@ -779,7 +806,7 @@ class NAS_MODEL(nn.Module):
             self._skip_key = key
         return self._skip_val
 
-    def _body(self, y, mg, mask_hard=None):
+    def _body(self, y, mg, mask_hard=None, sc=None):
         """All MyAggregationLayer blocks (reference wdsr_b.py:111-117 with :517-546 per block) through ONE autograd node:
         weight-norm, masks, gates, softmax and the latency terms are a few batched ops over the stacked kinds.
         Returns (y NHWC, speed_accu (1,))."""
@@ -789,16 +816,22 @@ class NAS_MODEL(nn.Module):
         skipped = [] if self.training else self._skip_flags()
         idx = [i for i in range(nball) if not (skipped and skipped[i])]   # eval: a skipped block only applies the (idempotent 0/1) global mask
         # latency head, reference speed_estimator.py:57-76 (raw alpha, rounding() with its default least_channel = 8)
-        with torch.no_grad():
-            c_mask = (rounding(self.mask.weight.detach()) if mask_hard is None or self.mask.least_channel != 8 else mask_hard).sum()
-            W = K["split.weight"].detach().view(nball, -1)                                           # (NB, F)
-            hard = (W >= 0.5).float()
-            top8 = ((W.unsqueeze(1) > W.unsqueeze(2)).sum(2) < 8).float()      # W >= 8th largest of its row (ties kept), as rounding()
-            c_split = torch.where(hard.sum(1, keepdim=True) >= 8, hard, top8).sum(1)
-            A = K["alpha"].detach()                                                                  # (NB, 3)
-            speed_curr = ((c_split + 0.2 * c_mask).view(-1, 1) * _const(dev, (9.0, 25.0, 49.0)).view(1, 3) * A / 40).sum(1)
+        if sc is not None:
+            speed_curr = sc["speed_curr"]
+        else:
+            with torch.no_grad():
+                c_mask = (rounding(self.mask.weight.detach()) if mask_hard is None or self.mask.least_channel != 8 else mask_hard).sum()
+                W = K["split.weight"].detach().view(nball, -1)                                           # (NB, F)
+                hard = (W >= 0.5).float()
+                top8 = ((W.unsqueeze(1) > W.unsqueeze(2)).sum(2) < 8).float()  # W >= 8th largest of its row (ties kept), as rounding()
+                c_split = torch.where(hard.sum(1, keepdim=True) >= 8, hard, top8).sum(1)
+                A = K["alpha"].detach()                                                                  # (NB, 3)
+                speed_curr = ((c_split + 0.2 * c_mask).view(-1, 1) * _const(dev, (9.0, 25.0, 49.0)).view(1, 3) * A / 40).sum(1)
         if self.training:
-            gates = _GateFunction.apply(K["alpha1"].view(-1), K["alpha2"].view(-1))
+            if sc is not None:
+                gates = _GateValues.apply(K["alpha1"].view(-1), K["alpha2"].view(-1), sc["gates"])
+            else:
+                gates = _GateFunction.apply(K["alpha1"].view(-1), K["alpha2"].view(-1))
             gd = gates.detach()
             self.kind("beta1", self.flat.data).copy_(gd[:, 0:1])                                     # reference :521-523,:534
             self.kind("beta2", self.flat.data).copy_(gd[:, 1:2])
@@ -815,7 +848,8 @@ class NAS_MODEL(nn.Module):
 
         SW = K["split.weight"].view(nbk, -1)                                                         # (nb, F)
         SWd = SW.detach()
-        MS = SW - (SWd - (SWd >= 0.5).float())                   # BinaryConv2d(least_channel=0): value 0/1, gradient 1
+        hard = sc["ms_hard"] if sc is not None and nbk == nball else (SWd >= 0.5).float()
+        MS = SW - (SWd - hard)                                   # BinaryConv2d(least_channel=0): value 0/1, gradient 1
         P = F.softmax(K["alpha"], dim=1)
         if self.training:
             BETA = gates

@@ -152,3 +152,39 @@ def test_nas_bf16_mode_tracks_fp32_mode(units):
         worst = max(worst, e)
         assert e <= 0.15, (k, e)
     print(f"worst per-tensor grad rel L2 {worst:.2e}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("units", [24, 32])
+def test_nas_scalars_kernel_matches_torch_formulas(units):
+    """sr_nas_scalars (one launch) against the reference's formulas as torch ops: rounding() with its top-8 fallback and ties
+    (models/ops.py:33-43), the gates (wdsr_b.py:517-534) and the latency head (speed_estimator.py:57-76); bit-exact masks."""
+    from mobilesuperresolution_amd import _lib as L
+    from mobilesuperresolution_amd.models.ops import rounding
+    torch.manual_seed(5)
+    nb, f = 16, units
+    dev = torch.device("cuda", 0)
+    for case in range(6):
+        scale = (1.0, 0.55, 0.4, 1.0, 0.3, 0.7)[case]
+        mask_w = (torch.rand(f, 1, 1, 1, device=dev) * scale).contiguous()
+        split = (torch.rand(nb, f, device=dev) * scale).contiguous()
+        if case >= 3:                                   # ties at the 8th value, exact 0.5s
+            split = torch.round(split * 8) / 8
+            mask_w = torch.round(mask_w * 8) / 8
+        alpha = torch.rand(nb, 3, device=dev)
+        a1, a2 = torch.rand(nb, device=dev), torch.rand(nb, device=dev)
+        a2[::3] = a1[::3]                               # alpha1 == alpha2 -> gate (1, 0)
+        out = torch.empty(f + 1 + nb * (f + 4), device=dev)
+        L.check(L.lib().sr_nas_scalars(mask_w.data_ptr(), split.data_ptr(), alpha.data_ptr(), a1.data_ptr(), a2.data_ptr(), nb, f,
+                                       out.data_ptr(), L.stream_ptr()), "scalars")
+        mh = rounding(mask_w)
+        assert torch.equal(out[:f], mh.reshape(-1))
+        assert float(out[f]) == float(mh.sum())
+        o = f + 1
+        assert torch.equal(out[o:o + nb * f].view(nb, f), (split >= 0.5).float())
+        cs = torch.stack([rounding(split[b].view(f, 1, 1, 1)).sum() for b in range(nb)])
+        assert torch.equal(out[o + nb * f:o + nb * (f + 1)], cs)
+        sp = ((cs + 0.2 * mh.sum()).view(-1, 1) * torch.tensor([9.0, 25.0, 49.0], device=dev).view(1, 3) * alpha / 40).sum(1)
+        torch.testing.assert_close(out[o + nb * (f + 1):o + nb * (f + 2)], sp, rtol=1e-6, atol=1e-6)
+        g1 = (a1 >= a2).float()
+        assert torch.equal(out[o + nb * (f + 2):].view(nb, 2), torch.stack([g1, 1 - g1], dim=1))
