@@ -244,7 +244,8 @@ int sr_nas_dw_wgrad(const void* yin, const void* GZ, const float* dwp, float* pa
  * [nb][wgs][slab] at byte strides pw_bs / dw_bs.  *g_in receives the pointer (g_tmp[0] or g_tmp[1]) that holds the gradient at ys[0]. */
 /* 0/1 masks, gates and latency terms of a supernet step, values only (models/ops.py:33-43, wdsr_b.py:517-534,
  * speed_estimator.py:57-76).  split_w (nb, F), alpha (nb, 3), alpha1 / alpha2 (nb).
- * out: mask_hard[F] | c_mask | ms_hard[nb][F] | c_split[nb] | speed_curr[nb] | gates[nb][2]  (F + 1 + nb (F + 4) floats) */
+ * out: mask_hard[F] | c_mask | ms_hard[nb][F] | c_split[nb] | speed_curr[nb] | gates[nb][2]  (F + 1 + nb (F + 4) floats).
+ * One workgroup; -1 if (nb + 1) F > 4096. */
 int sr_nas_scalars(const float* mask_w, const float* split_w, const float* alpha, const float* alpha1, const float* alpha2,
                    int nb, int F, float* out, sr_stream_t stream);
 int sr_nas_body_fwd(void* ys, void* V, const float* dwp, long dwp_bs, const void* frags, long frags_bs, const float* tabs,

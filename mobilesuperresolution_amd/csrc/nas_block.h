@@ -747,29 +747,37 @@ __global__ __launch_bounds__(768) void nas_dw_wgrad3_kernel(const __bf16* __rest
 // fewer than 8 entries strictly larger.
 // out: mask_hard[F] | c_mask | ms_hard[nb][F] (split.weight >= 0.5) | c_split[nb] | speed_curr[nb] | gates[nb][2]
 // ---------------------------------------------------------------------------------------------
-SR_DEV float nas_rounding8(const float* __restrict__ w, int F, int i) {
-  int pass = 0, above = 0;
-  const float wi = w[i];
-  for (int j = 0; j < F; ++j) { pass += w[j] >= 0.5f; above += w[j] > wi; }
-  return pass >= 8 ? (wi >= 0.5f ? 1.f : 0.f) : (above < 8 ? 1.f : 0.f);
-}
+constexpr int NAS_SCALARS_MAX = 4096;                 // (nb + 1) * F values staged in LDS
 
-__global__ __launch_bounds__(256) void nas_scalars_kernel(const float* __restrict__ mask_w, const float* __restrict__ split_w,
-                                                          const float* __restrict__ alpha, const float* __restrict__ alpha1,
-                                                          const float* __restrict__ alpha2, int nb, int F,
-                                                          float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void nas_scalars_kernel(const float* __restrict__ mask_w, const float* __restrict__ split_w,
+                                                           const float* __restrict__ alpha, const float* __restrict__ alpha1,
+                                                           const float* __restrict__ alpha2, int nb, int F,
+                                                           float* __restrict__ out) {
+  __shared__ float Wl[NAS_SCALARS_MAX], Rl[NAS_SCALARS_MAX];      // rows 0 .. nb - 1: split.weight of the blocks; row nb: the global mask
   float* const mask_hard = out;
   float* const c_mask_o = out + F;
   float* const ms_hard = out + F + 1;
   float* const c_split_o = ms_hard + (size_t)nb * F;
   float* const speed = c_split_o + nb;
   float* const gates = speed + nb;
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
-  for (int i = tid; i < F; i += nthr) mask_hard[i] = nas_rounding8(mask_w, F, i);
-  for (int i = tid; i < nb * F; i += nthr) ms_hard[i] = split_w[i] >= 0.5f ? 1.f : 0.f;
+  const int tid = threadIdx.x, nthr = blockDim.x, total = (nb + 1) * F;
+  for (int i = tid; i < total; i += nthr) Wl[i] = i < nb * F ? split_w[i] : mask_w[i - nb * F];
+  __syncthreads();
+  for (int e = tid; e < total; e += nthr) {
+    const int row = e / F;
+    const float* w = Wl + row * F;
+    const float wi = Wl[e];
+    int pass = 0, above = 0;
+    for (int j = 0; j < F; ++j) { pass += w[j] >= 0.5f; above += w[j] > wi; }
+    const float hard = wi >= 0.5f ? 1.f : 0.f, r8 = pass >= 8 ? hard : (above < 8 ? 1.f : 0.f);
+    Rl[e] = r8;
+    if (row < nb) ms_hard[e] = hard;
+    else mask_hard[e - nb * F] = r8;
+  }
+  __syncthreads();
   for (int b = tid; b < nb; b += nthr) {
     float cm = 0.f, cs = 0.f;
-    for (int i = 0; i < F; ++i) { cm += nas_rounding8(mask_w, F, i); cs += nas_rounding8(split_w + (size_t)b * F, F, i); }
+    for (int i = 0; i < F; ++i) { cm += Rl[nb * F + i]; cs += Rl[b * F + i]; }
     if (b == 0) *c_mask_o = cm;
     c_split_o[b] = cs;
     const float t = cs + 0.2f * cm;
@@ -779,4 +787,3 @@ __global__ __launch_bounds__(256) void nas_scalars_kernel(const float* __restric
     gates[2 * b + 1] = 1.f - g1;
   }
 }
-

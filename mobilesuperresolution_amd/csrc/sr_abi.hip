@@ -989,9 +989,9 @@ extern "C" int sr_param_grads(const float* flat, float* dsrc, float* gflat, cons
 
 extern "C" int sr_nas_scalars(const float* mask_w, const float* split_w, const float* alpha, const float* alpha1,
                               const float* alpha2, int nb, int F, float* out, sr_stream_t stream) {
-  if (!mask_w || !split_w || !alpha || !alpha1 || !alpha2 || !out || nb <= 0 || F < 8 || F > 1024) return -2;
-  const int blocks = (nb * F + 255) / 256;
-  hipLaunchKernelGGL(nas_scalars_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mask_w, split_w, alpha, alpha1, alpha2, nb,
+  if (!mask_w || !split_w || !alpha || !alpha1 || !alpha2 || !out || nb <= 0 || F < 8) return -2;
+  if ((long)(nb + 1) * F > NAS_SCALARS_MAX) return -1;
+  hipLaunchKernelGGL(nas_scalars_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask_w, split_w, alpha, alpha1, alpha2, nb,
                      F, out);
   SR_HIP_CHECK_LAUNCH();
   return 0;

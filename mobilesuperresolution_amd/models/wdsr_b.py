@@ -775,7 +775,8 @@ class NAS_MODEL(nn.Module):
         x = x.contiguous().float()
         f, dt = self.num_residual_units, self.hot_dtype
         y = _HeadFunction.apply(x, self.head.weight(), self.head.bias, f, dt, self.image_mean)
-        sc = self._scalars() if self.mask.least_channel == 8 and not os.environ.get("SR_NAS_TORCH_PREP") else None
+        sc = (self._scalars() if self.mask.least_channel == 8 and (self.num_blocks + 1) * self.num_residual_units <= 4096
+              and not os.environ.get("SR_NAS_TORCH_PREP") else None)
         # once: the mask's value and the latency head's count
         mask_hard = sc["mask_hard"] if sc is not None else rounding(self.mask.weight.detach(), self.mask.least_channel)
         mg = self.mask.effective(mask_hard)

@@ -24,9 +24,10 @@ def test_batched_rows_rounding_equals_per_row():
     """the (NB, F) form used by NAS_MODEL._body for the latency terms"""
     g = torch.Generator().manual_seed(1)
     W = torch.rand(16, 32, generator=g) * 0.7
-    kth = torch.topk(W, 8, dim=1).values[:, -1:]
+    W[3, :12] = W[3, 0]                                                             # ties around the 8th value
     hard = (W >= 0.5).float()
-    batched = torch.where(hard.sum(1, keepdim=True) >= 8, hard, (W >= kth).float())
+    top8 = ((W.unsqueeze(1) > W.unsqueeze(2)).sum(2) < 8).float()                   # topk-free: fewer than 8 strictly larger
+    batched = torch.where(hard.sum(1, keepdim=True) >= 8, hard, top8)
     for i in range(W.shape[0]):
         assert torch.equal(batched[i], O.rounding(W[i].view(-1, 1, 1, 1), 8).view(-1))
 
@@ -125,3 +126,77 @@ def test_flat_body_parameter_views_and_freezing():
     m.kernel_grad(False)
     a = m.kind("alpha")
     assert torch.equal(a.sum(1), torch.ones(3)) and set(a.unique().tolist()) == {0.0, 1.0} and "alpha" in m._frozen
+
+
+def test_nas_prep_tables_drive_weight_norm_pack_and_gradient_scatter():
+    """packing.nas_prep_tables (the tables behind sr_param_pack / sr_param_grads on the supernet body), with the four
+    kernels of csrc/wdsr_prep.h restated in numpy: the source rows equal torch's weight-norm of every conv + the biases,
+    the operand gathers equal the index_select route, and slab sums scattered and pushed through the weight-norm
+    backward equal autograd's gradient of the same weights."""
+    import numpy as np
+    from mobilesuperresolution_amd import packing as P
+    from mobilesuperresolution_amd.models.wdsr_b import _body_kinds
+    f, nb = 24, 3
+    rng = np.random.default_rng(0)
+    layout, off = [], 0
+    for name, shape in _body_kinds(f):
+        n = nb * int(np.prod(shape))
+        layout.append((name, off, n, (nb,) + tuple(shape)))
+        off += n
+    flat = rng.standard_normal(off).astype(np.float32)
+    t = P.nas_prep_tables(f, nb, tuple(layout))
+    o, size, ds = t["off"], t["size"], t["ds"]
+    lay = {name: (o_, n_, shp) for name, o_, n_, shp in layout}
+    kind = lambda name, src=flat: src[lay[name][0]:lay[name][0] + lay[name][1]].reshape(lay[name][2])
+    # --- wn_src_kernel restated
+    src = np.zeros(nb * size, np.float32)
+    for v_off, g_off, K, dst in t["chan_tab"]:
+        v = flat[v_off:v_off + K]
+        src[dst:dst + K] = v * (flat[g_off] / np.sqrt((v.astype(np.float64) ** 2).sum()))
+    for a, b, dst in t["bias_tab"]:
+        assert b == -1
+        src[dst] = flat[a]
+    src = src.reshape(nb, size)
+    for ki, k in enumerate((3, 5, 7)):
+        for j, col, K in ((0, o[f"wdw{k}"], k * k), (2, o["wpw"] + ki * f * f, f)):
+            v = torch.from_numpy(kind(f"body.{k}.0.body.{j}.weight_v").reshape(nb * f, -1))
+            g = torch.from_numpy(kind(f"body.{k}.0.body.{j}.weight_g").reshape(nb * f, 1))
+            w = torch._weight_norm(v, g, 0).reshape(nb, f * K).numpy()
+            np.testing.assert_allclose(src[:, col:col + f * K], w, rtol=2e-6, atol=1e-7)
+            bcol = o["bdw" if j == 0 else "bpw"] + ki * f
+            np.testing.assert_array_equal(src[:, bcol:bcol + f], kind(f"body.{k}.0.body.{j}.bias"))
+    # --- unpack_all_kernel + wn_bwd_kernel restated, against autograd
+    base = P.nas_tables(f)
+    wgs = 3
+    part_pw = rng.standard_normal((nb, wgs, base["pw_slab"])).astype(np.float32)
+    part_dw = rng.standard_normal((nb, wgs, base["dw_slab"])).astype(np.float32)
+    dsrc = np.zeros((nb, ds), np.float32)
+    dsrc[:, t["pw_dst"]] = part_pw.sum(1)[:, t["pw_sidx"]]
+    dsrc[:, t["dw_dst"]] = part_dw.sum(1)[:, t["dw_sidx"]]
+    spw, sdw = part_pw.sum(1), part_dw.sum(1)
+    np.testing.assert_array_equal(dsrc[:, o["wpw"]:o["wpw"] + 3 * f * f], spw[:, base["g_wpw"]])
+    np.testing.assert_array_equal(dsrc[:, t["extra"]["r"]:t["extra"]["r"] + 3 * f], spw[:, base["g_r"]])
+    np.testing.assert_array_equal(dsrc[:, t["extra"]["sxy"]], spw[:, base["sxy"]])
+    np.testing.assert_array_equal(dsrc[:, o["wdw7"]:o["wdw7"] + 49 * f], sdw[:, base["g_wdw"][2]])
+    np.testing.assert_array_equal(dsrc[:, t["extra"]["sB"]:t["extra"]["sB"] + f], sdw[:, base["g_sB"]])
+    gflat = np.zeros_like(flat)
+    dflat = dsrc.reshape(-1)
+    for v_off, g_off, K, dst in t["chan_bwd"]:
+        v, dw = flat[v_off:v_off + K].astype(np.float64), dflat[dst:dst + K].astype(np.float64)
+        ss, dot = (v * v).sum(), (v * dw).sum()
+        nrm = np.sqrt(ss)
+        gflat[v_off:v_off + K] = (flat[g_off] / nrm) * (dw - v * dot / ss)
+        gflat[g_off] = dot / nrm
+    for a, b, dst in t["bias_bwd"]:
+        gflat[a] = dflat[dst]
+    k, j = 5, 2
+    v = torch.from_numpy(kind(f"body.{k}.0.body.{j}.weight_v").reshape(nb * f, -1)).requires_grad_(True)
+    g = torch.from_numpy(kind(f"body.{k}.0.body.{j}.weight_g").reshape(nb * f, 1)).requires_grad_(True)
+    up = torch.from_numpy(dsrc[:, o["wpw"] + f * f:o["wpw"] + 2 * f * f].reshape(nb * f, f).copy())
+    torch._weight_norm(v, g, 0).backward(up)
+    np.testing.assert_allclose(kind(f"body.{k}.0.body.{j}.weight_v", gflat).reshape(nb * f, -1), v.grad.numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(kind(f"body.{k}.0.body.{j}.weight_g", gflat).reshape(nb * f, 1), g.grad.numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_array_equal(kind("body.3.0.body.0.bias", gflat), dsrc[:, o["bdw"]:o["bdw"] + f])
+    # kinds no table names keep a zero gradient from this route
+    for name in ("alpha", "beta", "alpha1", "alpha2", "split.weight"):
+        assert not kind(name, gflat).any()
