@@ -188,3 +188,45 @@ def test_nas_scalars_kernel_matches_torch_formulas(units):
         torch.testing.assert_close(out[o + nb * (f + 1):o + nb * (f + 2)], sp, rtol=1e-6, atol=1e-6)
         g1 = (a1 >= a2).float()
         assert torch.equal(out[o + nb * (f + 2):].view(nb, 2), torch.stack([g1, 1 - g1], dim=1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_nas_native_plumbing_equals_torch_route(monkeypatch, dtype):
+    """sr_param_pack / sr_param_grads / sr_nas_scalars (the default route of a training step) against the same step with the
+    weight-norm, gathers, slab sums, masks and gates as torch ops (SR_NAS_TORCH_PREP=1): outputs and gradients agree to
+    rounding / summation order (fp32) or to one bf16 rounding of a weight (bf16)."""
+    from mobilesuperresolution_amd.models import get_model
+    torch.manual_seed(21)
+    m = get_model(_nas_ns(num_blocks=4, num_residual_units=32, hot_dtype=dtype))
+    g = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        m.mask.weight.copy_(torch.rand(32, 1, 1, 1, generator=g) * 0.7 + 0.25)
+        for blk in m.body:
+            blk.split.weight.copy_(torch.rand(32, 1, 1, 1, generator=g) * 0.55 + 0.1)   # rows with fewer than 8 channels >= 0.5 too
+        m.body[2].alpha1.fill_(1.5)
+    m = m.cuda().train()
+    x = torch.rand(2, 3, 24, 36, generator=g).cuda()
+    hr = torch.rand(2, 3, 96, 144, generator=g).cuda()
+    res = []
+    for torch_route in (False, True):
+        if torch_route:
+            monkeypatch.setenv("SR_NAS_TORCH_PREP", "1")
+        else:
+            monkeypatch.delenv("SR_NAS_TORCH_PREP", raising=False)
+        m.zero_grad(set_to_none=True)
+        out, speed = m(x)
+        (torch.nn.functional.l1_loss(out, hr) + 0.1 * speed.sum()).backward()
+        res.append((out.detach().clone(), speed.detach().clone(), {k: v.clone() for k, v in m.named_reference_tensors(grads=True)
+                                                                   if v is not None},
+                    m.mask.weight.grad.clone()))
+    (o0, s0, g0, mg0), (o1, s1, g1, mg1) = res
+    # (the two weight-norm kernels round differently in the last bit, so not torch.equal)
+    tol = 2e-6 if dtype == "fp32" else 1e-2
+    assert float((o0 - o1).abs().max()) <= tol * float(o1.abs().max())
+    torch.testing.assert_close(s0, s1, rtol=1e-6, atol=0)
+    assert set(g0) == set(g1)
+    for k in g0:
+        scale = max(float(g1[k].abs().max()), 1e-12)
+        assert float((g0[k] - g1[k]).abs().max()) <= (2e-5 if dtype == "fp32" else 2e-2) * scale, k
+    torch.testing.assert_close(mg0, mg1, rtol=1e-4 if dtype == "fp32" else 2e-2, atol=1e-7 if dtype == "fp32" else 1e-4)
