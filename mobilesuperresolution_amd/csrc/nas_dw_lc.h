@@ -205,6 +205,116 @@ __global__ __launch_bounds__(512) void nas_dw_fwd_lc_kernel(const __bf16* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// The block's forward in ONE launch (bf16): the depthwise part as nas_dw_fwd_lc_kernel, whose three outputs V_k go to an LDS
+// tile [k][pixel][32] instead of 2-byte global stores; after one barrier the tile is (a) written to V with 16-byte stores
+// (the backward needs it) and (b) the B operand of the pointwise part (nas_pw_fwd_kernel's arithmetic, reading LDS it did
+// not have to stage).  Saves the second launch, its 14 MB read of V and its staging latency; results are bit-identical to the
+// two-kernel route.  9 waves: 24 row units over 9 waves are the same three rounds as over 8, and the pointwise part has
+// one 32-pixel tile per wave.  grid = (tiles, N).
+// ---------------------------------------------------------------------------------------------
+template <int F>
+__global__ __launch_bounds__(576) void nas_block_fwd_kernel(const __bf16* __restrict__ yin, __bf16* __restrict__ V,
+                                                            __bf16* __restrict__ y, const float* __restrict__ dwp,
+                                                            const __bf16* __restrict__ frags, const float* __restrict__ tabs,
+                                                            const float* __restrict__ scal, int H, int W, int tiles_x, long vstride) {
+  typedef __bf16 T;
+  typedef NasCfg<F> C;
+  typedef NasLcCfg<F> D;
+  typedef typename FragOf<T>::type FragT;
+  typedef typename FragOf<T>::half_type HalfT;
+  constexpr int NTHREADS = 576;
+  __shared__ __attribute__((aligned(16))) unsigned XE[D::XP_DW];
+  __shared__ __attribute__((aligned(16))) unsigned XO[D::XP_DW];
+  __shared__ __attribute__((aligned(16))) unsigned WP[D::NWP * 32];
+  __shared__ __attribute__((aligned(16))) T VT[3 * C::VT_ELEMS];
+  const int tid = threadIdx.x, lane = tid & 63, ch = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+  const size_t img = (size_t)n * H * W * F;
+  nas_pack_weights<F>(WP, dwp, tid, NTHREADS, false);
+  nas_stage_pairs<F, NTHREADS>(XE, XO, yin + img, dwp + C::M1, H, W, ty0, tx0, tid);
+  __syncthreads();
+  {
+    NasLcW w;
+    w.template load<F>(WP, ch);
+    const float b3 = dwp[C::BD + ch], b5 = dwp[C::BD + 32 + ch], b7 = dwp[C::BD + 64 + ch];
+    const unsigned* X = half ? XO : XE;
+    const bool chan = ch < F;
+#pragma unroll 1
+    for (int u = wave; u < D::NUNIT; u += NTHREADS / 64) {
+      const int oy = u >> 1, ox0 = (u & 1) * D::UW + half;                // this lane's first column (its parity = half)
+      const unsigned* base = X + (size_t)((oy * C::PW + ox0) >> 1) * F + (chan ? ch : 0);
+      unsigned win[7][4];
+#pragma unroll
+      for (int ty = 0; ty < 7; ++ty)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) win[ty][t] = base[(ty * (C::PW / 2) + t) * F];
+#pragma unroll
+      for (int s = 0; s < D::UW / 2; ++s) {
+        float z3 = b3, z5 = b5, z7 = b7;
+        nas_lc_point(z3, z5, z7, win, w);
+        T* v = VT + (oy * C::TW + ox0 + 2 * s) * 32 + ch;               // channels >= F: the zero rows the MFMA wants
+        v[0] = chan ? (T)fmaxf(z3, 0.f) : (T)0.f;
+        v[C::VT_ELEMS] = chan ? (T)fmaxf(z5, 0.f) : (T)0.f;
+        v[2 * C::VT_ELEMS] = chan ? (T)fmaxf(z7, 0.f) : (T)0.f;
+        if (s + 1 < D::UW / 2) {                         // slide two columns: three pairs per row stay, one is read
+#pragma unroll
+          for (int ty = 0; ty < 7; ++ty) {
+            win[ty][0] = win[ty][1];
+            win[ty][1] = win[ty][2];
+            win[ty][2] = win[ty][3];
+            win[ty][3] = base[(ty * (C::PW / 2) + s + 4) * F];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // (a) V_k to global: (branch, pixel, 8-channel chunk) items, 16 bytes each
+  for (int idx = tid; idx < 3 * C::NPXC * C::FC; idx += NTHREADS) {
+    const int k = idx / (C::NPXC * C::FC), q = idx - k * (C::NPXC * C::FC), pc = q / C::FC, c = q - pc * C::FC;
+    const int Y = ty0 + pc / C::TW, X = tx0 + pc % C::TW;
+    if (Y < H && X < W)
+      *reinterpret_cast<FragT*>(V + k * vstride + img + ((size_t)Y * W + X) * F + c * 8) =
+          *reinterpret_cast<const FragT*>(VT + k * C::VT_ELEMS + pc * 32 + c * 8);
+  }
+  // (b) pointwise + mix: y = mg*yin + beta2 * ms * sum_k p_k relu(pw_k V_k + bp_k)
+  const int r = lane & 31, hh = half;
+  const int ot = wave;
+  const int oy = (ot / (C::TW / 8)) * 4 + (r >> 3), ox = (ot % (C::TW / 8)) * 8 + (r & 7);
+  const int pc = oy * C::TW + ox;
+  float S[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) S[i] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    f32x16 acc = load_cinit(tabs + k * 32, hh);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      acc = mma16<T>(load_wfrag<T>(frags, 2 * k + s, lane), lds_chunk<T>(VT + k * C::VT_ELEMS, pc * 32 + (2 * s + hh) * 8), acc);
+    const float p = scal[k];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S[i] += p * fmaxf(acc[i], 0.f);
+  }
+  const int Y = ty0 + oy, X = tx0 + ox;
+  if (Y < H && X < W) {
+    const size_t o = img + ((size_t)Y * W + X) * F;
+    const f32x16 ms = load_cinit(tabs + 96, hh), mg = load_cinit(tabs + 128, hh);
+    const float b2 = scal[3];
+    float xin[16];
+    nas_load_rows<T, F>(xin, yin + o, hh);
+#pragma unroll
+    for (int g = 0; g < C::FC; ++g) {
+      HalfT v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (T)(mg[4 * g + j] * xin[4 * g + j] + b2 * ms[4 * g + j] * S[4 * g + j]);
+      *reinterpret_cast<HalfT*>(y + o + g * 8 + hh * 4) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // depthwise backward, lane = channel: g_br = sum_k dw_k^T(GZ_k) (flipped stencils), g_x = gy + ms g_br, g_yin = mg g_x;
 // slab tail: dbd[3][32] (pixel sums of GZ_k) | sA[c] = sum g_br mg yin | sB[c] = sum g_x yin   (the dW part of the slab is
 // nas_dw_wgrad_kernel's).  The three stencils read three DIFFERENT images here, so a tile is three passes (stage GZ_k,

@@ -1003,10 +1003,28 @@ extern "C" int sr_nas_body_fwd(void* ys, void* V, const float* dwp, long dwp_bs,
                                sr_stream_t stream) {
   if (!ys || !V || !dwp || !frags || !tabs || !scal || nb <= 0 || N <= 0 || H <= 0 || W <= 0) return -2;
   const size_t act = (size_t)N * H * W * F * (dtype == SR_DTYPE_BF16 ? 2 : 4);
+  // bf16: depthwise + pointwise of a block from one launch (csrc/nas_dw_lc.h nas_block_fwd_kernel); SR_NAS_FWD_SPLIT=1 (read per
+  // call, so a test can compare both routes in one process): the two kernels
+  const bool fused = dtype == SR_DTYPE_BF16 && (F == 24 || F == 32) && N <= 65535 && !getenv("SR_NAS_FWD_SPLIT") && !getenv("SR_NAS_DW_VALU");
   for (int i = 0; i < nb; ++i) {
     char* yi = (char*)ys + (size_t)i * act;
     char* Vi = (char*)V + (size_t)i * 3 * act;
     int rc;
+    if (fused) {
+      typedef NasCfg<24> C;
+      const int tx = (W + C::TW - 1) / C::TW;
+      const dim3 g(tx * ((H + C::TH - 1) / C::TH), N);
+      const long vs = (long)N * H * W * F;
+      const float* dw_i = (const float*)((const char*)dwp + (size_t)i * dwp_bs);
+      const __bf16* fr_i = (const __bf16*)((const char*)frags + (size_t)i * frags_bs);
+      const float* tb_i = (const float*)((const char*)tabs + (size_t)i * tabs_bs);
+      const float* sc_i = (const float*)((const char*)scal + (size_t)i * scal_bs);
+      hipStream_t st = (hipStream_t)stream;
+      if (F == 24) hipLaunchKernelGGL((nas_block_fwd_kernel<24>), g, dim3(576), 0, st, (const __bf16*)yi, (__bf16*)Vi, (__bf16*)(yi + act), dw_i, fr_i, tb_i, sc_i, H, W, tx, vs);
+      else hipLaunchKernelGGL((nas_block_fwd_kernel<32>), g, dim3(576), 0, st, (const __bf16*)yi, (__bf16*)Vi, (__bf16*)(yi + act), dw_i, fr_i, tb_i, sc_i, H, W, tx, vs);
+      SR_HIP_CHECK_LAUNCH();
+      continue;
+    }
     if ((rc = sr_nas_dw_fwd(yi, Vi, (const float*)((const char*)dwp + (size_t)i * dwp_bs), N, H, W, F, dtype, stream))) return rc;
     if ((rc = sr_nas_pw_fwd(yi, Vi, yi + act, (const char*)frags + (size_t)i * frags_bs, (const float*)((const char*)tabs + (size_t)i * tabs_bs),
                             (const float*)((const char*)scal + (size_t)i * scal_bs), N, H, W, F, dtype, stream)))

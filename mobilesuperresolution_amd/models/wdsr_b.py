@@ -781,9 +781,12 @@ class NAS_MODEL(nn.Module):
         mask_hard = sc["mask_hard"] if sc is not None else rounding(self.mask.weight.detach(), self.mask.least_channel)
         mg = self.mask.effective(mask_hard)
         y, speed_accu = self._body(y, mg, mask_hard, sc)
-        y = (y.float() * mg.view(1, 1, 1, -1)).to(dt)                         # y = self.mask(y) before the tail (:118-119)
+        # y = self.mask(y) before the tail (:118-119): the mask's value is exactly 0 / 1 per channel, so it is applied to the
+        # tail conv's INPUT-channel weights (one op on 10 k weights, exact) instead of to the activations (three passes over
+        # the feature map each way); the straight-through gradient reaches mask.weight through the product's autograd
+        wt = self.tail.weight() * mg.view(1, -1, 1, 1)
         btot = self.tail.bias + self.skip.bias + self.image_mean
-        out = _TailFunction.apply(y, x, self.tail.weight(), self.skip.weight(), btot, self.scale, self.image_mean)
+        out = _TailFunction.apply(y, x, wt, self.skip.weight(), btot, self.scale, self.image_mean)
         return out, speed_accu
 
     def _scalars(self):

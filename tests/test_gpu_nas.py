@@ -230,3 +230,33 @@ def test_nas_native_plumbing_equals_torch_route(monkeypatch, dtype):
         scale = max(float(g1[k].abs().max()), 1e-12)
         assert float((g0[k] - g1[k]).abs().max()) <= (2e-5 if dtype == "fp32" else 2e-2) * scale, k
     torch.testing.assert_close(mg0, mg1, rtol=1e-4 if dtype == "fp32" else 2e-2, atol=1e-7 if dtype == "fp32" else 1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("units", [24, 32])
+def test_nas_fused_block_forward_is_bit_identical_to_two_kernels(monkeypatch, units):
+    """nas_block_fwd_kernel (depthwise + pointwise of a block in one launch, V through an LDS tile) against the two-kernel
+    route (SR_NAS_FWD_SPLIT=1): output, saved V (through the gradients) -- ragged image, masks partly off"""
+    from mobilesuperresolution_amd.models import get_model
+    torch.manual_seed(31)
+    m = get_model(_nas_ns(num_blocks=3, num_residual_units=units, hot_dtype="bf16"))
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        m.mask.weight.copy_(torch.rand(units, 1, 1, 1, generator=g) * 0.7 + 0.25)
+        for blk in m.body:
+            blk.split.weight.copy_(torch.rand(units, 1, 1, 1, generator=g) * 0.7 + 0.2)
+    m = m.cuda().train()
+    x = torch.rand(3, 3, 29, 50, generator=g).cuda()
+    hr = torch.rand(3, 3, 116, 200, generator=g).cuda()
+    res = []
+    for split in (False, True):
+        if split:
+            monkeypatch.setenv("SR_NAS_FWD_SPLIT", "1")
+        else:
+            monkeypatch.delenv("SR_NAS_FWD_SPLIT", raising=False)
+        m.zero_grad(set_to_none=True)
+        out, speed = m(x)
+        (torch.nn.functional.l1_loss(out, hr) + 0.1 * speed.sum()).backward()
+        res.append((out.detach().clone(), m.flat.grad.clone(), m.mask.weight.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
