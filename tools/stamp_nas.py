@@ -39,7 +39,7 @@ s = raw[..., 0] * 10.0
 nst = int((s[0, 0] > 0).sum()); nw = int((s[0, :, 0] > 0).sum()); print("stamps", nst, "waves", nw, raw[0, 0, :8, 0])
 t0 = s[:, :nw, 0].min()
 print(f"{wgs} workgroups, {nw} waves, {nst} stamps; first start -> last end {s[:, :nw, nst - 1].max() - t0:.0f} ns; start spread {s[:, 0, 0].max() - t0:.0f} ns")
-names = ["stage V + weights", "sxy pass", "items", "scale + zero slab", "turns", "sxy reduce + store"]
+names = ["stage V + weights", "sxy pass", "items", "scale + butterfly + barrier", "slab copies + barrier", "sum copies + store"]
 for k in range(nst - 1):
     d = s[:, :nw, k + 1] - s[:, :nw, k]
     print("%-20s median %6.0f ns  p10 %6.0f  p90 %6.0f   per-wave median: %s" % (names[k] if k < len(names) else k, np.median(d),
