@@ -10,6 +10,7 @@
 #include "conv3x3.h"
 #include "nas_block.h"
 #include "nas_dw_lc.h"
+#include "nas_bwd_fused.h"
 #include "flow_warp.h"
 #include "metrics.h"
 #include "patches.h"
@@ -1041,6 +1042,12 @@ extern "C" int sr_nas_body_bwd(const void* ys, const void* V, const void* g_out,
     return -2;
   const size_t act = (size_t)N * H * W * F * (dtype == SR_DTYPE_BF16 ? 2 : 4);
   const void* g = g_out;
+  // bf16, one tile per workgroup: csrc/nas_bwd_fused.h; SR_NAS_BWD_SPLIT=1 (read per call, so a test can compare both routes in one
+  // process): the separate kernels
+  const int tx_f = (W + NasCfg<24>::TW - 1) / NasCfg<24>::TW, tpi_f = tx_f * ((H + NasCfg<24>::TH - 1) / NasCfg<24>::TH);
+  const long vs_f = (long)N * H * W * F;
+  const bool fused = dtype == SR_DTYPE_BF16 && (F == 24 || F == 32) && (long)N * tpi_f <= wgs && !getenv("SR_NAS_BWD_SPLIT") &&
+                     !getenv("SR_NAS_WGRAD_SPLIT") && !getenv("SR_NAS_DW_VALU");
   for (int i = nb - 1; i >= 0; --i) {
     void* gin = (i & 1) ? g_tmp1 : g_tmp0;
     const char* yi = (const char*)ys + (size_t)i * act;
@@ -1048,6 +1055,19 @@ extern "C" int sr_nas_body_bwd(const void* ys, const void* V, const void* g_out,
     const float* dw_i = (const float*)((const char*)dwp + (size_t)i * dwp_bs);
     float* pdw = (float*)((char*)part_dw + (size_t)i * dw_bs);
     int rc;
+    if (fused) {                                       // pointwise backward + depthwise weight gradients from one launch
+      const float* tb_i = (const float*)((const char*)tabs + (size_t)i * tabs_bs);
+      const float* sc_i = (const float*)((const char*)scal + (size_t)i * scal_bs);
+      const __bf16* fr_i = (const __bf16*)((const char*)frags + (size_t)i * frags_bs);
+      float* ppw = (float*)((char*)part_pw + (size_t)i * pw_bs);
+      hipStream_t st = (hipStream_t)stream;
+      if (F == 24) hipLaunchKernelGGL((nas_block_bwd_a_kernel<24>), dim3(wgs), dim3(768), 0, st, (const __bf16*)yi, (const __bf16*)Vi, (const __bf16*)g, (__bf16*)GZ, fr_i, tb_i, sc_i, dw_i, ppw, pdw, N, H, W, tx_f, tpi_f, vs_f);
+      else hipLaunchKernelGGL((nas_block_bwd_a_kernel<32>), dim3(wgs), dim3(768), 0, st, (const __bf16*)yi, (const __bf16*)Vi, (const __bf16*)g, (__bf16*)GZ, fr_i, tb_i, sc_i, dw_i, ppw, pdw, N, H, W, tx_f, tpi_f, vs_f);
+      SR_HIP_CHECK_LAUNCH();
+      if ((rc = sr_nas_dw_bwd(yi, GZ, g, gin, dw_i, pdw, wgs, N, H, W, F, dtype, stream))) return rc;
+      g = gin;
+      continue;
+    }
     if ((rc = sr_nas_pw_bwd(yi, Vi, g, GZ, (const char*)frags + (size_t)i * frags_bs, (const float*)((const char*)tabs + (size_t)i * tabs_bs),
                             (const float*)((const char*)scal + (size_t)i * scal_bs), (float*)((char*)part_pw + (size_t)i * pw_bs), wgs, N,
                             H, W, F, dtype, stream)))

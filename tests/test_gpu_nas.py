@@ -260,3 +260,43 @@ def test_nas_fused_block_forward_is_bit_identical_to_two_kernels(monkeypatch, un
         res.append((out.detach().clone(), m.flat.grad.clone(), m.mask.weight.grad.clone()))
     assert torch.equal(res[0][0], res[1][0])
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("units", [24, 32])
+def test_nas_fused_block_backward_matches_separate_kernels(monkeypatch, units):
+    """nas_block_bwd_a_kernel (pointwise backward + depthwise weight gradients in one launch, GZ handed over through the LDS
+    tile) against the separate kernels (SR_NAS_BWD_SPLIT=1): the data gradient (through GZ) and the depthwise weight
+    gradients are bit-identical, the pointwise sums agree to summation order -- ragged image, masks partly off"""
+    from mobilesuperresolution_amd.models import get_model
+    torch.manual_seed(33)
+    m = get_model(_nas_ns(num_blocks=3, num_residual_units=units, hot_dtype="bf16"))
+    g = torch.Generator().manual_seed(10)
+    with torch.no_grad():
+        m.mask.weight.copy_(torch.rand(units, 1, 1, 1, generator=g) * 0.7 + 0.25)
+        for blk in m.body:
+            blk.split.weight.copy_(torch.rand(units, 1, 1, 1, generator=g) * 0.7 + 0.2)
+    m = m.cuda().train()
+    x = torch.rand(3, 3, 29, 50, generator=g).cuda().requires_grad_(True)
+    hr = torch.rand(3, 3, 116, 200, generator=g).cuda()
+    res = []
+    for split in (False, True):
+        if split:
+            monkeypatch.setenv("SR_NAS_BWD_SPLIT", "1")
+        else:
+            monkeypatch.delenv("SR_NAS_BWD_SPLIT", raising=False)
+        m.zero_grad(set_to_none=True)
+        x.grad = None
+        out, speed = m(x)
+        (torch.nn.functional.l1_loss(out, hr) + 0.1 * speed.sum()).backward()
+        res.append((dict((k, v.clone()) for k, v in m.named_reference_tensors(grads=True) if v is not None), m.head.weight_v.grad.clone()))
+    (ga, ha), (gb, hb) = res
+    assert torch.equal(ha, hb)                          # the head's gradient has passed through every block's data gradient
+    assert set(ga) == set(gb)
+    for k in ga:
+        if ".body.0.weight_v" in k or ".body.0.weight_g" in k:       # depthwise convs: same MFMA sequence
+            scale = max(float(gb[k].abs().max()), 1e-12)
+            assert float((ga[k] - gb[k]).abs().max()) <= 1e-6 * scale, k
+        else:
+            scale = max(float(gb[k].abs().max()), 1e-12)
+            assert float((ga[k] - gb[k]).abs().max()) <= 2e-5 * scale, k
