@@ -247,7 +247,14 @@ int sr_nas_dw_wgrad(const void* yin, const void* GZ, const float* dwp, float* pa
  * out: mask_hard[F] | c_mask | ms_hard[nb][F] | c_split[nb] | speed_curr[nb] | gates[nb][2]  (F + 1 + nb (F + 4) floats).
  * One workgroup; -1 if (nb + 1) F > 4096. */
 int sr_nas_scalars(const float* mask_w, const float* split_w, const float* alpha, const float* alpha1, const float* alpha2,
-                   int nb, int F, float* out, sr_stream_t stream);
+                   int nb, int F, float* out, float* src, long src_stride, int off_mg, float* scal, sr_stream_t stream);
+/* optional outputs of sr_nas_scalars (NULL: skipped): `src` -- the mask columns mg | ms | mg ms | 0 | 1 (3 F + 2 floats at column
+ * off_mg) of nb operand-source rows of src_stride floats (sr_param_pack gathers them); `scal` -- nb x {softmax(alpha)[3], gate2}.
+ * sr_nas_mask_grads: the gradients of the masks / gates / branch weights from the sums the block kernels left in d(source)
+ * (columns off_r: r[3][F], off_sxy, off_sA: [F], off_sB: [F] of rows of `ds` floats), ms (nb, F), p (nb, 3), beta (nb, 2):
+ * out = g_p[nb][3] | g_beta[nb][2] | g_ms[nb][F] | g_mg[F]   (wdsr_b.py:517-546 differentiated) */
+int sr_nas_mask_grads(const float* dsrc, long ds, int off_r, int off_sxy, int off_sA, int off_sB, const float* ms, const float* p,
+                      const float* beta, int nb, int F, float* out, sr_stream_t stream);
 int sr_nas_body_fwd(void* ys, void* V, const float* dwp, long dwp_bs, const void* frags, long frags_bs, const float* tabs,
                     long tabs_bs, const float* scal, long scal_bs, int nb, int N, int H, int W, int F, int dtype,
                     sr_stream_t stream);

@@ -55,7 +55,8 @@ SIGNATURES = {
     "sr_patch_gather": ([_P, _P, _P, _P, _I, _I, _I, _P], _I),
     "sr_param_pack": ([_P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P], _I),
     "sr_param_grads": ([_P, _P, _P, _P, _I, _P, _I, _P, _I, _P], _I),
-    "sr_nas_scalars": ([_P] * 5 + [_I, _I, _P, _P], _I),
+    "sr_nas_scalars": ([_P] * 5 + [_I, _I, _P, _P, _L, _I, _P, _P], _I),
+    "sr_nas_mask_grads": ([_P, _L, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P], _I),
     "sr_nas_body_fwd": ([_P, _P, _P, _L, _P, _L, _P, _L, _P, _L] + [_I] * 6 + [_P], _I),
     "sr_nas_body_bwd": ([_P] * 7 + [_L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L] + [_I] * 7 + [_P, _P], _I),
     "sr_psnr": ([_P, _P, _P, _P] + [_I] * 7 + [_P], _I),

@@ -752,7 +752,8 @@ constexpr int NAS_SCALARS_MAX = 4096;                 // (nb + 1) * F values sta
 __global__ __launch_bounds__(1024) void nas_scalars_kernel(const float* __restrict__ mask_w, const float* __restrict__ split_w,
                                                            const float* __restrict__ alpha, const float* __restrict__ alpha1,
                                                            const float* __restrict__ alpha2, int nb, int F,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, float* __restrict__ src, long src_stride,
+                                                           int off_mg, float* __restrict__ scal) {
   __shared__ float Wl[NAS_SCALARS_MAX], Rl[NAS_SCALARS_MAX];      // rows 0 .. nb - 1: split.weight of the blocks; row nb: the global mask
   float* const mask_hard = out;
   float* const c_mask_o = out + F;
@@ -785,5 +786,58 @@ __global__ __launch_bounds__(1024) void nas_scalars_kernel(const float* __restri
     const float g1 = alpha1[b] >= alpha2[b] ? 1.f : 0.f;
     gates[2 * b] = g1;
     gates[2 * b + 1] = 1.f - g1;
+    if (scal) {                                        // per-block kernel scalars: softmax(alpha) | beta2 (training: the gate)
+      const float a0 = alpha[3 * b], a1 = alpha[3 * b + 1], a2 = alpha[3 * b + 2], mx = fmaxf(a0, fmaxf(a1, a2));
+      const float e0 = expf(a0 - mx), e1 = expf(a1 - mx), e2 = expf(a2 - mx), inv = 1.f / (e0 + e1 + e2);
+      scal[4 * b] = e0 * inv; scal[4 * b + 1] = e1 * inv; scal[4 * b + 2] = e2 * inv; scal[4 * b + 3] = 1.f - g1;
+    }
+  }
+  if (src) {                                           // the mask columns of the operand source rows: mg | ms | mg ms | 0 | 1
+    for (int e = tid; e < nb * F; e += nthr) {
+      const int b = e / F, c = e - b * F;
+      float* row = src + (size_t)b * src_stride + off_mg;
+      const float mg = Rl[nb * F + c], ms = Wl[e] >= 0.5f ? 1.f : 0.f;
+      row[c] = mg; row[F + c] = ms; row[2 * F + c] = mg * ms;
+      if (c == 0) { row[3 * F] = 0.f; row[3 * F + 1] = 1.f; }
+    }
+  }
+}
+
+// gradients of the masks / gates / branch weights from the sums the block kernels left in d(source):
+// q_k = sum_c ms[c] r_k[c]; g_p = beta2 q; g_beta = (sxy, sxy + sum_k p_k q_k); g_ms = sA + beta2 sum_k p_k r_k; g_mg = sum_b sB
+// out: g_p[nb][3] | g_beta[nb][2] | g_ms[nb][F] | g_mg[F]
+__global__ __launch_bounds__(1024) void nas_mask_grads_kernel(const float* __restrict__ dsrc, long ds, int off_r, int off_sxy,
+                                                              int off_sA, int off_sB, const float* __restrict__ ms,
+                                                              const float* __restrict__ p, const float* __restrict__ beta, int nb,
+                                                              int F, float* __restrict__ out) {
+  float* const g_p = out;
+  float* const g_beta = out + 3 * nb;
+  float* const g_ms = g_beta + 2 * nb;
+  float* const g_mg = g_ms + (size_t)nb * F;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int b = tid; b < nb; b += nthr) {
+    const float* row = dsrc + (size_t)b * ds;
+    const float b2 = beta[2 * b + 1];
+    float pq = 0.f;
+    for (int k = 0; k < 3; ++k) {
+      float q = 0.f;
+      for (int c = 0; c < F; ++c) q += ms[b * F + c] * row[off_r + k * F + c];
+      g_p[3 * b + k] = b2 * q;
+      pq += p[3 * b + k] * q;
+    }
+    g_beta[2 * b] = row[off_sxy];
+    g_beta[2 * b + 1] = row[off_sxy] + pq;
+  }
+  for (int e = tid; e < nb * F; e += nthr) {
+    const int b = e / F, c = e - b * F;
+    const float* row = dsrc + (size_t)b * ds;
+    float v = 0.f;
+    for (int k = 0; k < 3; ++k) v += p[3 * b + k] * row[off_r + k * F + c];
+    g_ms[e] = row[off_sA + c] + beta[2 * b + 1] * v;
+  }
+  for (int c = tid; c < F; c += nthr) {
+    float v = 0.f;
+    for (int b = 0; b < nb; ++b) v += dsrc[(size_t)b * ds + off_sB + c];
+    g_mg[c] = v;
   }
 }

@@ -989,11 +989,22 @@ extern "C" int sr_param_grads(const float* flat, float* dsrc, float* gflat, cons
 }
 
 extern "C" int sr_nas_scalars(const float* mask_w, const float* split_w, const float* alpha, const float* alpha1,
-                              const float* alpha2, int nb, int F, float* out, sr_stream_t stream) {
-  if (!mask_w || !split_w || !alpha || !alpha1 || !alpha2 || !out || nb <= 0 || F < 8) return -2;
+                              const float* alpha2, int nb, int F, float* out, float* src, long src_stride, int off_mg, float* scal,
+                              sr_stream_t stream) {
+  if (!mask_w || !split_w || !alpha || !alpha1 || !alpha2 || !out || nb <= 0 || F < 8 || (src && (src_stride <= 0 || off_mg < 0)))
+    return -2;
   if ((long)(nb + 1) * F > NAS_SCALARS_MAX) return -1;
   hipLaunchKernelGGL(nas_scalars_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask_w, split_w, alpha, alpha1, alpha2, nb,
-                     F, out);
+                     F, out, src, src_stride, off_mg, scal);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sr_nas_mask_grads(const float* dsrc, long ds, int off_r, int off_sxy, int off_sA, int off_sB, const float* ms,
+                                 const float* p, const float* beta, int nb, int F, float* out, sr_stream_t stream) {
+  if (!dsrc || !ms || !p || !beta || !out || nb <= 0 || F <= 0 || ds <= 0) return -2;
+  hipLaunchKernelGGL(nas_mask_grads_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dsrc, ds, off_r, off_sxy, off_sA, off_sB, ms,
+                     p, beta, nb, F, out);
   SR_HIP_CHECK_LAUNCH();
   return 0;
 }

@@ -268,7 +268,7 @@ class _NasBodyNative(torch.autograd.Function):
     Inputs: flat (the body parameter), mg (F,), MS (nb, F), P (nb, 3), BETA (nb, 2), layout / frozen of the model."""
 
     @staticmethod
-    def forward(ctx, y0, flat, mg, MS, P_, BETA, layout, frozen):
+    def forward(ctx, y0, flat, mg, MS, P_, BETA, layout, frozen, src_pre=None, scal_pre=None):
         n, h, w, f = y0.shape
         nb = MS.shape[0]
         dev, dt = y0.device, y0.dtype
@@ -276,9 +276,12 @@ class _NasBodyNative(torch.autograd.Function):
         o, size = tb["off"], tb["size"]
         mgf, MSf = mg.detach().float(), MS.detach().float()
         flatd = flat.detach()
-        src = torch.empty((nb, size), dtype=torch.float32, device=dev)
-        src[:, o["mg"]:o["zero"]] = torch.cat([mgf.reshape(1, f).expand(nb, f), MSf, mgf.reshape(1, f) * MSf], dim=1)
-        src[:, o["zero"]:] = _const(dev, (0.0, 1.0))
+        if src_pre is not None:                         # mask columns already written by sr_nas_scalars
+            src = src_pre
+        else:
+            src = torch.empty((nb, size), dtype=torch.float32, device=dev)
+            src[:, o["mg"]:o["zero"]] = torch.cat([mgf.reshape(1, f).expand(nb, f), MSf, mgf.reshape(1, f) * MSf], dim=1)
+            src[:, o["zero"]:] = _const(dev, (0.0, 1.0))
         code = L.DTYPE_CODE[dt]
         dwp = torch.empty((nb, tb["dwp"].numel()), dtype=torch.float32, device=dev)
         frags = torch.empty((nb, tb["frags"].numel()), dtype=dt, device=dev)
@@ -289,7 +292,7 @@ class _NasBodyNative(torch.autograd.Function):
         L.launch("sr_param_pack", L.lib().sr_param_pack, flatd.data_ptr(), src.data_ptr(), tb["chan_tab"].data_ptr(),
                  tb["chan_tab"].shape[0], tb["bias_tab"].data_ptr(), tb["bias_const"].data_ptr(), tb["bias_tab"].shape[0], segs, 3,
                  code, L.stream_ptr())
-        scal = torch.cat([P_.detach().float(), BETA.detach().float()[:, 1:2]], dim=1).contiguous()
+        scal = scal_pre if scal_pre is not None else torch.cat([P_.detach().float(), BETA.detach().float()[:, 1:2]], dim=1).contiguous()
         ys = torch.empty((nb + 1, n, h, w, f), dtype=dt, device=dev)
         ys[0] = y0
         V = torch.empty((nb, 3, n, h, w, f), dtype=dt, device=dev)
@@ -300,7 +303,8 @@ class _NasBodyNative(torch.autograd.Function):
         ctx.layout, ctx.frozen = layout, frozen
         # the parameter values the weight-norm backward needs are the ones of THIS forward: keep a snapshot only if the
         # caller may write the parameter in place before backward (forward() itself rewrites beta1 / beta2, which no table names)
-        ctx.save_for_backward(ys, V, dwp, frags, tabs, scal, MSf, P_.detach().float(), BETA.detach().float(), flat)
+        ctx.save_for_backward(ys, V, dwp, frags, tabs, scal, MSf.contiguous(), P_.detach().float().contiguous(),
+                              BETA.detach().float().contiguous(), flat)      # (eval: BETA is an expanded constant)
         return ys[nb]
 
     @staticmethod
@@ -339,16 +343,14 @@ class _NasBodyNative(torch.autograd.Function):
         for name, o_, n_, _shape in ctx.layout:                                        # kernel_grad(False) & co: frozen kinds
             if name in ctx.frozen and name.startswith("body."):
                 gflat[o_:o_ + n_].zero_()
-        r = dsrc[:, ex["r"]:ex["r"] + 3 * f].view(nb, 3, f)                            # r_k[c] = sum gy[c] relu(u_k)[c]
-        sxy = dsrc[:, ex["sxy"]]
-        sA, sB = dsrc[:, ex["sA"]:ex["sA"] + f], dsrc[:, ex["sB"]:ex["sB"] + f]
-        b2 = BETA[:, 1]
-        q = (r * MS.view(nb, 1, f)).sum(2)                                             # q_k = sum_c ms[c] r_k[c]
-        g_p = b2.view(nb, 1) * q
-        g_beta = torch.stack([sxy, sxy + (P_ * q).sum(1)], dim=1)
-        g_ms = sA + b2.view(nb, 1) * (P_.view(nb, 3, 1) * r).sum(1)
-        g_mg = sB.sum(0)
-        return g, gflat, g_mg, g_ms, g_p, g_beta, None, None
+        # q_k = sum_c ms[c] r_k[c]; g_p = beta2 q; g_beta = (sxy, sxy + sum_k p_k q_k); g_ms = sA + beta2 sum_k p_k r_k;
+        # g_mg = sum_b sB -- one launch over the extra columns of d(source)
+        mgr = torch.empty(nb * (5 + f) + f, dtype=torch.float32, device=dev)
+        L.launch("sr_nas_mask_grads", L.lib().sr_nas_mask_grads, dsrc.data_ptr(), ds, ex["r"], ex["sxy"], ex["sA"], ex["sB"],
+                 MS.data_ptr(), P_.data_ptr(), BETA.data_ptr(), nb, f, mgr.data_ptr(), L.stream_ptr())
+        g_p, g_beta = mgr[:3 * nb].view(nb, 3), mgr[3 * nb:5 * nb].view(nb, 2)
+        g_ms, g_mg = mgr[5 * nb:5 * nb + nb * f].view(nb, f), mgr[5 * nb + nb * f:]
+        return g, gflat, g_mg, g_ms, g_p, g_beta, None, None, None, None
 
 
 class _GateFunction(torch.autograd.Function):
@@ -794,13 +796,19 @@ class NAS_MODEL(nn.Module):
         mask_hard (F,1,1,1), ms_hard (nb, F), speed_curr (nb,), gates (nb, 2) of one buffer"""
         nb, f = self.num_blocks, self.num_residual_units
         fl = self.flat.detach()
+        off = P.nas_tables(f)["off"]
         out = torch.empty(f + 1 + nb * (f + 4), dtype=torch.float32, device=fl.device)
+        # the operand-source rows of the body (their mask columns are written here, the weights by sr_param_pack) and the
+        # per-block kernel scalars softmax(alpha) | gate2
+        src = torch.empty((nb, off["size"]), dtype=torch.float32, device=fl.device)
+        scal = torch.empty((nb, 4), dtype=torch.float32, device=fl.device)
         L.launch("sr_nas_scalars", L.lib().sr_nas_scalars, self.mask.weight.detach().data_ptr(),
                  self.kind("split.weight", fl).data_ptr(), self.kind("alpha", fl).data_ptr(), self.kind("alpha1", fl).data_ptr(),
-                 self.kind("alpha2", fl).data_ptr(), nb, f, out.data_ptr(), L.stream_ptr())
+                 self.kind("alpha2", fl).data_ptr(), nb, f, out.data_ptr(), src.data_ptr(), src.stride(0), off["mg"], scal.data_ptr(),
+                 L.stream_ptr())
         o = f + 1
         return dict(mask_hard=out[:f].view(f, 1, 1, 1), ms_hard=out[o:o + nb * f].view(nb, f),
-                    speed_curr=out[o + nb * (f + 1):o + nb * (f + 2)], gates=out[o + nb * (f + 2):].view(nb, 2))
+                    speed_curr=out[o + nb * (f + 1):o + nb * (f + 2)], gates=out[o + nb * (f + 2):].view(nb, 2), src=src, scal=scal)
 
     def _skip_flags(self):
         """eval-time gates alpha1 >= alpha2 of all blocks as host bools, read back once per parameter version"""
@@ -861,7 +869,8 @@ class NAS_MODEL(nn.Module):
             BETA = _const(dev, (0.0, 1.0)).view(1, 2).expand(nbk, 2)
         if nbk == nball and not os.environ.get("SR_NAS_TORCH_PREP"):
             # every block runs: weight-norm / packing / gradient gathers native too (two launches each way)
-            return _NasBodyNative.apply(y, self.flat, mg, MS, P, BETA, self._layout, self._frozen), speed_accu
+            pre = (sc["src"], sc["scal"] if self.training else None) if sc is not None else (None, None)
+            return _NasBodyNative.apply(y, self.flat, mg, MS, P, BETA, self._layout, self._frozen, *pre), speed_accu
 
         def wn(k, j):                                # weight-normalised conv j (0 depthwise, 2 pointwise) of branch k
             v, g = K[f"body.{k}.0.body.{j}.weight_v"], K[f"body.{k}.0.body.{j}.weight_g"]

@@ -175,8 +175,10 @@ def test_nas_scalars_kernel_matches_torch_formulas(units):
         a1, a2 = torch.rand(nb, device=dev), torch.rand(nb, device=dev)
         a2[::3] = a1[::3]                               # alpha1 == alpha2 -> gate (1, 0)
         out = torch.empty(f + 1 + nb * (f + 4), device=dev)
+        src = torch.full((nb, 3 * f + 7), -7.0, device=dev)                # mask columns at offset 3 of rows of 3 F + 7
+        scal = torch.empty(nb, 4, device=dev)
         L.check(L.lib().sr_nas_scalars(mask_w.data_ptr(), split.data_ptr(), alpha.data_ptr(), a1.data_ptr(), a2.data_ptr(), nb, f,
-                                       out.data_ptr(), L.stream_ptr()), "scalars")
+                                       out.data_ptr(), src.data_ptr(), src.stride(0), 3, scal.data_ptr(), L.stream_ptr()), "scalars")
         mh = rounding(mask_w)
         assert torch.equal(out[:f], mh.reshape(-1))
         assert float(out[f]) == float(mh.sum())
@@ -188,6 +190,11 @@ def test_nas_scalars_kernel_matches_torch_formulas(units):
         torch.testing.assert_close(out[o + nb * (f + 1):o + nb * (f + 2)], sp, rtol=1e-6, atol=1e-6)
         g1 = (a1 >= a2).float()
         assert torch.equal(out[o + nb * (f + 2):].view(nb, 2), torch.stack([g1, 1 - g1], dim=1))
+        mg, ms = mh.reshape(1, f).expand(nb, f), (split >= 0.5).float()
+        expect = torch.cat([mg, ms, mg * ms, torch.zeros(nb, 1, device=dev), torch.ones(nb, 1, device=dev)], dim=1)
+        assert torch.equal(src[:, 3:3 + 3 * f + 2], expect) and bool((src[:, :3] == -7).all()) and bool((src[:, 3 * f + 5:] == -7).all())
+        torch.testing.assert_close(scal[:, :3], torch.softmax(alpha, dim=1), rtol=1e-6, atol=1e-7)
+        assert torch.equal(scal[:, 3], 1 - g1)
 
 
 @pytest.mark.gpu
