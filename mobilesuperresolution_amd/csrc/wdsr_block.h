@@ -882,6 +882,8 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block2_b
   const size_t img = (size_t)n * H * W * F;
   const size_t tile_g = (size_t)n * gridDim.x + tile;            // tile index of the saved dt images
 
+  SR_STAMP_DECL;
+  SR_STAMP();
   WSrc<T, true> wsa, wsb;
   wsa.p = WL;
   wsb.p = WL + NWL * 512;
@@ -901,7 +903,9 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block2_b
     // slack rows of the dxB image (read by the padded taps of phase 2, never written by phase 1)
     for (int i = tid; i < (C::NPXH_PAD + 2 - C::NPXH) * C::F; i += NTHREADS) DY1[C::NPXH * C::F + i] = (T)0.f;
   }
+  SR_STAMP();
   __syncthreads();
+  SR_STAMP();
 
   // ---- phase 1: dxB on the 14x26 region ----
   {
@@ -943,9 +947,11 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block2_b
       }
     }
   }
+  SR_STAMP();
   __syncthreads();
   ra.store(XA, tid);
   __syncthreads();
+  SR_STAMP();
 
   // ---- phase 2: dxA on the core ----
   if (wave < C::NPT_O) {
@@ -973,6 +979,7 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block2_b
       for (int g = 0; g < C::FC; ++g) stream_store(reinterpret_cast<HalfT*>(o + g * 8 + hh * 4), acc_group<T>(dxacc, g));
     }
   }
+  SR_STAMP();
 }
 
 // =============================================================================================
