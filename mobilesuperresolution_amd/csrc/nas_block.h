@@ -815,18 +815,20 @@ __global__ __launch_bounds__(1024) void nas_mask_grads_kernel(const float* __res
   float* const g_ms = g_beta + 2 * nb;
   float* const g_mg = g_ms + (size_t)nb * F;
   const int tid = threadIdx.x, nthr = blockDim.x;
+  __shared__ float Q[3 * 1024];
+  for (int i = tid; i < 3 * nb && i < 3 * 1024; i += nthr) {       // q_k of block b: one thread each, its loads independent
+    const int b = i / 3, kq = i - 3 * b;
+    const float* row = dsrc + (size_t)b * ds + off_r + kq * F;
+    float q = 0.f;
+    for (int c = 0; c < F; ++c) q += ms[b * F + c] * row[c];
+    Q[i] = q;
+    g_p[i] = beta[2 * b + 1] * q;
+  }
+  __syncthreads();
   for (int b = tid; b < nb; b += nthr) {
-    const float* row = dsrc + (size_t)b * ds;
-    const float b2 = beta[2 * b + 1];
-    float pq = 0.f;
-    for (int k = 0; k < 3; ++k) {
-      float q = 0.f;
-      for (int c = 0; c < F; ++c) q += ms[b * F + c] * row[off_r + k * F + c];
-      g_p[3 * b + k] = b2 * q;
-      pq += p[3 * b + k] * q;
-    }
-    g_beta[2 * b] = row[off_sxy];
-    g_beta[2 * b + 1] = row[off_sxy] + pq;
+    const float sxy = dsrc[(size_t)b * ds + off_sxy];
+    g_beta[2 * b] = sxy;
+    g_beta[2 * b + 1] = sxy + p[3 * b] * Q[3 * b] + p[3 * b + 1] * Q[3 * b + 1] + p[3 * b + 2] * Q[3 * b + 2];
   }
   for (int e = tid; e < nb * F; e += nthr) {
     const int b = e / F, c = e - b * F;

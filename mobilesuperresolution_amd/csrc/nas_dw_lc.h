@@ -41,28 +41,35 @@ SR_DEV float nas_dot2(unsigned x, unsigned w, float acc) {
 
 // packed stencil weights WP[row][32 channels]: row = (stencil, window row, window column pair (0,1) (2,3) (4,5) (6,7));
 // `flip`: the data-gradient form (window tap (ty, tx) weighs with w[ks-1-ty][ks-1-tx])
-template <int F>
-SR_DEV void nas_pack_weights(unsigned* WP, const float* __restrict__ dwp, int tid, int nthreads, bool flip) {
+template <int F, int NT>
+SR_DEV void nas_pack_weights(unsigned* WP, const float* __restrict__ dwp, int tid, bool flip) {
   typedef NasLcCfg<F> D;
   typedef NasCfg<F> C;
-  for (int i = tid; i < D::NWP * 32; i += nthreads) {
+  constexpr int TOTAL = D::NWP * 32, IT = (TOTAL + NT - 1) / NT;
+  float v[IT][2];                                      // every load of a thread in flight before the first is packed
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int i = tid + it * NT;
     const int row = i >> 5, ch = i & 31;
     int ks, r, t, wbase;
     if (row < D::W5P) { ks = 7; r = row / 4; t = row % 4; wbase = C::W7; }
     else if (row < D::W3P) { ks = 5; r = (row - D::W5P) / 3; t = (row - D::W5P) % 3; wbase = C::W5; }
     else { ks = 3; r = (row - D::W3P) / 2; t = (row - D::W3P) % 2 + 1; wbase = C::W3; }
     const int off = 3 - ks / 2;                        // the stencil's first window column
-    float v[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int tx = 2 * t + h - off;                  // stencil column of window column 2 t + h
-      v[h] = 0.f;
-      if (tx >= 0 && tx < ks) {
+      v[it][h] = 0.f;
+      if (i < TOTAL && tx >= 0 && tx < ks) {
         const int rr = flip ? ks - 1 - r : r, cc = flip ? ks - 1 - tx : tx;
-        v[h] = dwp[wbase + (rr * ks + cc) * 32 + ch];
+        v[it][h] = dwp[wbase + (rr * ks + cc) * 32 + ch];
       }
     }
-    WP[i] = nas_pack2(v[0], v[1]);
+  }
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int i = tid + it * NT;
+    if (i < TOTAL) WP[i] = nas_pack2(v[it][0], v[it][1]);
   }
 }
 
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(512) void nas_dw_fwd_lc_kernel(const __bf16* __rest
   const int n = blockIdx.y, tile = blockIdx.x;
   const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
   const size_t img = (size_t)n * H * W * F;
-  nas_pack_weights<F>(WP, dwp, tid, 512, false);
+  nas_pack_weights<F, 512>(WP, dwp, tid, false);
   nas_stage_pairs<F, 512>(XE, XO, yin + img, dwp + C::M1, H, W, ty0, tx0, tid);
   __syncthreads();
   NasLcW w;
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(576) void nas_block_fwd_kernel(const __bf16* __rest
   const int n = blockIdx.y, tile = blockIdx.x;
   const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
   const size_t img = (size_t)n * H * W * F;
-  nas_pack_weights<F>(WP, dwp, tid, NTHREADS, false);
+  nas_pack_weights<F, NTHREADS>(WP, dwp, tid, false);
   nas_stage_pairs<F, NTHREADS>(XE, XO, yin + img, dwp + C::M1, H, W, ty0, tx0, tid);
   __syncthreads();
   {
@@ -366,7 +373,13 @@ __global__ __launch_bounds__(512) void nas_dw_bwd_lc_kernel(const __bf16* __rest
   __shared__ float GB[18 * 512];
   const int tid = threadIdx.x, lane = tid & 63, ch = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  nas_pack_weights<F>(WP, dwp, tid, 512, true);        // flipped: the data gradient
+  SR_STAMP_DECL;
+  SR_STAMP();
+  nas_pack_weights<F, 512>(WP, dwp, tid, true);        // flipped: the data gradient
+  if ((int)blockIdx.x < N * tiles_per_img) {           // the first tile's first image is staged under the same barrier
+    const int t0 = blockIdx.x, n0 = t0 / tiles_per_img, tile0 = t0 - n0 * tiles_per_img;
+    nas_stage_pairs<F, 512>(XE, XO, GZ + (size_t)n0 * H * W * F, nullptr, H, W, (tile0 / tiles_x) * C::TH, (tile0 % tiles_x) * C::TW, tid);
+  }
   __syncthreads();
   NasLcW w;
   w.template load<F>(WP, ch);
@@ -391,9 +404,13 @@ __global__ __launch_bounds__(512) void nas_dw_bwd_lc_kernel(const __bf16* __rest
     const size_t img = (size_t)n * H * W * F;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      __syncthreads();                                 // the previous pass is through with the pair images
-      nas_stage_pairs<F, 512>(XE, XO, GZ + k * vstride + img, nullptr, H, W, ty0, tx0, tid);
-      __syncthreads();
+      SR_STAMP();
+      if (!(k == 0 && t == (int)blockIdx.x)) {
+        __syncthreads();                               // the previous pass is through with the pair images
+        nas_stage_pairs<F, 512>(XE, XO, GZ + k * vstride + img, nullptr, H, W, ty0, tx0, tid);
+        __syncthreads();
+      }
+      SR_STAMP();
 #pragma unroll 1
       for (int i = 0; i < 3; ++i) {
         const int u = wave + 8 * i;
@@ -403,6 +420,18 @@ __global__ __launch_bounds__(512) void nas_dw_bwd_lc_kernel(const __bf16* __rest
         float g[6];
 #pragma unroll
         for (int s = 0; s < 6; ++s) g[s] = k == 0 ? 0.f : GB[(i * 6 + s) * 512 + tid];
+        // last pass: this unit's yin / gy values are fetched before the 7x7 window work, not after it
+        __bf16 yq[6], gq[6];
+        if (k == 2) {
+#pragma unroll
+          for (int s = 0; s < 6; ++s) {
+            const int Y = ty0 + oy, Xc = tx0 + ox0 + 2 * s;
+            const bool ok = chan && Y < H && Xc < W;
+            const size_t o = img + ((size_t)(ok ? Y : 0) * W + (ok ? Xc : 0)) * F + (ok ? ch : 0);
+            yq[s] = yin[o];
+            gq[s] = gy[o];
+          }
+        }
         if (k == 0) nas_lc_bwd_unit<3>(g, db[0], base, w3, F, C::PW / 2);
         else if (k == 1) nas_lc_bwd_unit<5>(g, db[1], base, w5, F, C::PW / 2);
         else nas_lc_bwd_unit<7>(g, db[2], base, w.w7, F, C::PW / 2);
@@ -415,7 +444,7 @@ __global__ __launch_bounds__(512) void nas_dw_bwd_lc_kernel(const __bf16* __rest
             const int Y = ty0 + oy, Xc = tx0 + ox0 + 2 * s;
             if (chan && Y < H && Xc < W) {
               const size_t o = img + ((size_t)Y * W + Xc) * F + ch;
-              const float yv = (float)yin[o], gv = (float)gy[o];
+              const float yv = (float)yq[s], gv = (float)gq[s];
               const float gx = gv + msc * g[s];
               gyin[o] = (__bf16)(mgc * gx);
               sA += g[s] * mgc * yv;
@@ -426,6 +455,7 @@ __global__ __launch_bounds__(512) void nas_dw_bwd_lc_kernel(const __bf16* __rest
       }
     }
   }
+  SR_STAMP();
   // ---- workgroup reduction of the per-lane sums: [wave][5][32] in LDS (the pair images are free now) ----
   __syncthreads();
   float* red = reinterpret_cast<float*>(XE);
@@ -442,4 +472,5 @@ __global__ __launch_bounds__(512) void nas_dw_bwd_lc_kernel(const __bf16* __rest
     for (int wv = 0; wv < 8; ++wv) s += red[wv * 160 + tid];
     partial[(size_t)blockIdx.x * C::DWB_SLAB + 83 * 32 + tid] = s;       // dbd[3][32] | sA[32] | sB[32]
   }
+  SR_STAMP();
 }

@@ -1002,7 +1002,7 @@ extern "C" int sr_nas_scalars(const float* mask_w, const float* split_w, const f
 
 extern "C" int sr_nas_mask_grads(const float* dsrc, long ds, int off_r, int off_sxy, int off_sA, int off_sB, const float* ms,
                                  const float* p, const float* beta, int nb, int F, float* out, sr_stream_t stream) {
-  if (!dsrc || !ms || !p || !beta || !out || nb <= 0 || F <= 0 || ds <= 0) return -2;
+  if (!dsrc || !ms || !p || !beta || !out || nb <= 0 || nb > 1024 || F <= 0 || ds <= 0) return -2;
   hipLaunchKernelGGL(nas_mask_grads_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dsrc, ds, off_r, off_sxy, off_sA, off_sB, ms,
                      p, beta, nb, F, out);
   SR_HIP_CHECK_LAUNCH();
