@@ -243,12 +243,14 @@ class _NasBodyFunction(torch.autograd.Function):
 _PREP_CACHE = {}
 
 
-def _nas_prep_dev_tables(Fch: int, nb: int, layout, device_index: int):
-    """packing.nas_prep_tables on the device + the constant columns of a source buffer (cached per geometry and device)"""
-    key = (Fch, nb, layout, device_index)
+def _nas_prep_dev_tables(Fch: int, nb: int, layout, device_index: int, blocks=None):
+    """packing.nas_prep_tables on the device (cached per geometry, set of running blocks and device)"""
+    key = (Fch, nb, layout, device_index, blocks)
     t = _PREP_CACHE.get(key)
     if t is None:
-        h = P.nas_prep_tables(Fch, nb, layout)
+        if len(_PREP_CACHE) > 64:                       # (a search visits few block subsets; bound the cache anyway)
+            _PREP_CACHE.clear()
+        h = P.nas_prep_tables(Fch, nb, layout, blocks)
         base = P.nas_tables(Fch)
         dev = torch.device("cuda", device_index)
         t = {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in h.items()}
@@ -268,11 +270,12 @@ class _NasBodyNative(torch.autograd.Function):
     Inputs: flat (the body parameter), mg (F,), MS (nb, F), P (nb, 3), BETA (nb, 2), layout / frozen of the model."""
 
     @staticmethod
-    def forward(ctx, y0, flat, mg, MS, P_, BETA, layout, frozen, src_pre=None, scal_pre=None):
+    def forward(ctx, y0, flat, mg, MS, P_, BETA, layout, frozen, src_pre=None, scal_pre=None, nb_total=None, blocks=None):
         n, h, w, f = y0.shape
         nb = MS.shape[0]
         dev, dt = y0.device, y0.dtype
-        tb = _nas_prep_dev_tables(f, nb, layout, dev.index if dev.index is not None else torch.cuda.current_device())
+        nbt = nb if nb_total is None else nb_total      # blocks of the model; `nb` of them (`blocks`) run
+        tb = _nas_prep_dev_tables(f, nbt, layout, dev.index if dev.index is not None else torch.cuda.current_device(), blocks)
         o, size = tb["off"], tb["size"]
         mgf, MSf = mg.detach().float(), MS.detach().float()
         flatd = flat.detach()
@@ -300,7 +303,7 @@ class _NasBodyNative(torch.autograd.Function):
                  dwp.stride(0) * dwp.element_size(), frags.data_ptr(), frags.stride(0) * frags.element_size(), tabs.data_ptr(),
                  tabs.stride(0) * tabs.element_size(), scal.data_ptr(), scal.stride(0) * scal.element_size(), nb, n, h, w, f, code,
                  L.stream_ptr())
-        ctx.layout, ctx.frozen = layout, frozen
+        ctx.layout, ctx.frozen, ctx.nbt, ctx.blocks = layout, frozen, nbt, blocks
         # the parameter values the weight-norm backward needs are the ones of THIS forward: keep a snapshot only if the
         # caller may write the parameter in place before backward (forward() itself rewrites beta1 / beta2, which no table names)
         ctx.save_for_backward(ys, V, dwp, frags, tabs, scal, MSf.contiguous(), P_.detach().float().contiguous(),
@@ -312,7 +315,7 @@ class _NasBodyNative(torch.autograd.Function):
         ys, V, dwp, frags, tabs, scal, MS, P_, BETA, flat = ctx.saved_tensors
         nb, n, h, w, f = V.shape[0], V.shape[2], V.shape[3], V.shape[4], V.shape[5]
         dev, dt = ys.device, ys.dtype
-        tb = _nas_prep_dev_tables(f, nb, ctx.layout, dev.index if dev.index is not None else torch.cuda.current_device())
+        tb = _nas_prep_dev_tables(f, ctx.nbt, ctx.layout, dev.index if dev.index is not None else torch.cuda.current_device(), ctx.blocks)
         code = L.DTYPE_CODE[dt]
         wgs = int(os.environ.get("SR_NAS_WGS", 256))
         GZ = torch.empty_like(V[0])
@@ -350,7 +353,7 @@ class _NasBodyNative(torch.autograd.Function):
                  MS.data_ptr(), P_.data_ptr(), BETA.data_ptr(), nb, f, mgr.data_ptr(), L.stream_ptr())
         g_p, g_beta = mgr[:3 * nb].view(nb, 3), mgr[3 * nb:5 * nb].view(nb, 2)
         g_ms, g_mg = mgr[5 * nb:5 * nb + nb * f].view(nb, f), mgr[5 * nb + nb * f:]
-        return g, gflat, g_mg, g_ms, g_p, g_beta, None, None, None, None
+        return g, gflat, g_mg, g_ms, g_p, g_beta, None, None, None, None, None, None
 
 
 class _GateFunction(torch.autograd.Function):
@@ -867,10 +870,11 @@ class NAS_MODEL(nn.Module):
             BETA = gates
         else:
             BETA = _const(dev, (0.0, 1.0)).view(1, 2).expand(nbk, 2)
-        if nbk == nball and not os.environ.get("SR_NAS_TORCH_PREP"):
-            # every block runs: weight-norm / packing / gradient gathers native too (two launches each way)
-            pre = (sc["src"], sc["scal"] if self.training else None) if sc is not None else (None, None)
-            return _NasBodyNative.apply(y, self.flat, mg, MS, P, BETA, self._layout, self._frozen, *pre), speed_accu
+        if not os.environ.get("SR_NAS_TORCH_PREP"):
+            # weight-norm / packing / gradient gathers native too (two launches each way); eval: only the blocks that run
+            pre = (sc["src"], sc["scal"] if self.training else None) if sc is not None and nbk == nball else (None, None)
+            return _NasBodyNative.apply(y, self.flat, mg, MS, P, BETA, self._layout, self._frozen, *pre, nball,
+                                        None if nbk == nball else tuple(idx)), speed_accu
 
         def wn(k, j):                                # weight-normalised conv j (0 depthwise, 2 pointwise) of branch k
             v, g = K[f"body.{k}.0.body.{j}.weight_v"], K[f"body.{k}.0.body.{j}.weight_g"]

@@ -484,11 +484,13 @@ def nas_tables(F: int):
                 g_sA=86 * 32 + np.arange(F), g_sB=87 * 32 + np.arange(F), pw_slab=3 * 1088 + 4, dw_slab=88 * 32, sxy=3 * 1088)
 
 
-def nas_prep_tables(F: int, nb: int, layout):
+def nas_prep_tables(F: int, nb: int, layout, blocks=None):
     """Tables for the native parameter plumbing of the supernet body (csrc/wdsr_prep.h through sr_param_pack / sr_param_grads).
     `layout`: NAS_MODEL._layout = (key suffix, offset in the flat parameter, count, (nb, ...) shape) per kind, stacked over
     blocks.  Source row of block b = nas_tables(F)['off'] columns; gradient row = the same columns followed by the extra sums
     r[3][F] | sxy | sA[F] | sB[F] the mask / gate gradients are made of.
+    `blocks`: the blocks that run, in order (eval drops skipped blocks; default all `nb`): row j of the source / gradient
+    buffers belongs to block blocks[j].
     Returns chan_tab int32[nb * 6F][4] = {v_off, g_off, K, dst}, bias_tab int32[nb * 6F][3] = {flat index, -1, dst},
     the two slab scatters (sidx, dst) and the row sizes."""
     t = nas_tables(F)
@@ -499,14 +501,14 @@ def nas_prep_tables(F: int, nb: int, layout):
     ds = size + 5 * F + 1
     chan, bias = [], []
     c = np.arange(F)
-    for b in range(nb):
+    for row, b in enumerate(range(nb) if blocks is None else blocks):
         for ki, k in enumerate((3, 5, 7)):
             for j, (K, dst0) in ((0, (k * k, o[f"wdw{k}"])), (2, (F, o["wpw"] + ki * F * F))):
                 ov, _n, _s = lay[f"body.{k}.0.body.{j}.weight_v"]
                 og, _n, _s = lay[f"body.{k}.0.body.{j}.weight_g"]
-                chan.append(np.stack([ov + (b * F + c) * K, og + b * F + c, np.full(F, K), b * size + dst0 + c * K], axis=1))
+                chan.append(np.stack([ov + (b * F + c) * K, og + b * F + c, np.full(F, K), row * size + dst0 + c * K], axis=1))
                 ob, _n, _s = lay[f"body.{k}.0.body.{j}.bias"]
-                bias.append(np.stack([ob + b * F + c, np.full(F, -1), b * size + o["bdw" if j == 0 else "bpw"] + ki * F + c], axis=1))
+                bias.append(np.stack([ob + b * F + c, np.full(F, -1), row * size + o["bdw" if j == 0 else "bpw"] + ki * F + c], axis=1))
     chan_tab = np.concatenate(chan).astype(np.int32)
     bias_tab = np.concatenate(bias).astype(np.int32)
     # the weight-norm backward reads d(src) at the same dst offsets but in rows of `ds` columns

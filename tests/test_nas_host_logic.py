@@ -200,3 +200,12 @@ def test_nas_prep_tables_drive_weight_norm_pack_and_gradient_scatter():
     # kinds no table names keep a zero gradient from this route
     for name in ("alpha", "beta", "alpha1", "alpha2", "split.weight"):
         assert not kind(name, gflat).any()
+    # eval with a skipped block: rows 0, 1 of the buffers belong to blocks 0 and 2
+    sub = P.nas_prep_tables(f, nb, tuple(layout), blocks=(0, 2))
+    full = t["chan_tab"].reshape(nb, 6 * f, 4)
+    got = sub["chan_tab"].reshape(2, 6 * f, 4)
+    np.testing.assert_array_equal(got[0], full[0])
+    np.testing.assert_array_equal(got[1][:, :3], full[2][:, :3])                    # block 2's parameters ...
+    np.testing.assert_array_equal(got[1][:, 3], full[2][:, 3] - size)               # ... into row 1
+    np.testing.assert_array_equal(sub["bias_tab"].reshape(2, 6 * f, 3)[1][:, 0], t["bias_tab"].reshape(nb, 6 * f, 3)[2][:, 0])
+
