@@ -5,6 +5,14 @@
 #pragma once
 #include "sr_common.h"
 
+// a wave inside its MFMA chains goes first at the issue arbiter; the other waves of the SIMD fill the gaps with their
+// epilogue VALU work (two-block backward-data kernel: 12.9 -> 12.6 us; results unchanged)
+#ifdef SR_BWD_NO_SETPRIO
+#define SR_BWD_PRIO(p) do {} while (0)
+#else
+#define SR_BWD_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#endif
+
 template <int F_, int E_, int L_>
 struct BlockCfg {
   static constexpr int F = F_, E = E_, L = L_;
@@ -913,9 +921,11 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block2_b
     const bool live = hp1 < C::NPXH;
     const int hp1c = live ? hp1 : 0;
     const int hy = hp1c / C::HW, hx = hp1c - hy * C::HW;
+    SR_BWD_PRIO(2);
     const f32x16 dtacc = dt_from_dy<T, C>(DY2, hy * P::W2 + hx, P::W2, wsb, LW3T, lane);
     const f32x16 dxacc = dx_from_dt<T, C>(dtacc, XBs, hp1c, DY2, ((hy + 1) * P::W2 + hx + 1) * C::F, wsb, LW2T, LW1T,
                                            LID, cib, lane);
+    SR_BWD_PRIO(0);
     if (live) {
       const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
       const bool inimg = (Y >= 0 && Y < H && X >= 0 && X < W);
@@ -958,8 +968,10 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block2_b
     const int ot = wave;
     const int oy = (ot / (C::TW / 8)) * 4 + (r >> 3), ox = (ot % (C::TW / 8)) * 8 + (r & 7);
     const int hbase = oy * C::HW + ox, pc = oy * C::TW + ox;
+    SR_BWD_PRIO(2);
     const f32x16 dtacc = dt_from_dy<T, C>(DY1, hbase, C::HW, wsa, LW3T, lane);
     const f32x16 dxacc = dx_from_dt<T, C>(dtacc, XA, pc, DY1, (hbase + C::HW + 1) * C::F, wsa, LW2T, LW1T, LID, cia, lane);
+    SR_BWD_PRIO(0);
     const int Y = ty0 + oy, X = tx0 + ox;
     if (dta) {
       T* o = dta + (tile_g * B::NPXC + pc) * C::LP;
