@@ -152,7 +152,9 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block_fw
     FragT xb[C::KS1];
 #pragma unroll
     for (int s = 0; s < C::KS1; ++s) xb[s] = lds_chunk<T>(Xs, hp * C::KX + (2 * s + hh) * 8);
+    SR_BWD_PRIO(2);
     const f32x16 tacc = t_from_xb<T, C, WSrc<T, WLDS>, (sizeof(T) == 2)>(xb, wsrc, cinit, lane);
+    SR_BWD_PRIO(0);
     bool valid = false;
     if (hp < C::NPXH) {
       const int hy = hp / C::HW, hx = hp - hy * C::HW;
@@ -186,6 +188,7 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block_fw
     const int oy = (ot / (C::TW / 8)) * 4 + (r >> 3), ox = (ot % (C::TW / 8)) * 8 + (r & 7);
     const int hbase = oy * C::HW + ox;
     f32x16 oacc = zero16();
+    SR_BWD_PRIO(2);
 #pragma unroll
     for (int s = 0; s < C::KS3; ++s) {
       const int q = 2 * s + hh;
@@ -200,6 +203,7 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_H)) void wdsr_block_fw
       }
       oacc = mma16<T>(wsrc.get(C::W3_OFF + s, lane), lds_chunk<T>(smem, off), oacc);
     }
+    SR_BWD_PRIO(0);
     const int Y = ty0 + oy, X = tx0 + ox;
     if (Y < H && X < W) {
       T* yo = y + (((size_t)n * H + Y) * W + X) * F;
@@ -404,6 +408,7 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_O)) void wdsr_block_bw
     const int ot = wave;
     const int oy = (ot / (C::TW / 8)) * 4 + (r >> 3), ox = (ot % (C::TW / 8)) * 8 + (r & 7);
     const int hbase = oy * C::HW + ox, pc = oy * C::TW + ox;
+    SR_BWD_PRIO(2);
     const f32x16 dtacc = dt_tile<T, C>(DYs, wsrc, LW3T, hbase, lane);
     if (dtsave) {                                  // keep dt of the core pixels (zero outside the image)
       const bool inimg = (ty0 + oy < H) && (tx0 + ox < W);
@@ -442,6 +447,7 @@ __global__ __launch_bounds__((64 * BlockCfg<F, E, L>::NPT_O)) void wdsr_block_bw
       if (c >= C::FC) c = 0;
       dxacc = mma16<T>(wsrc.get(LID + s, lane), lds_chunk<T>(DYs, (hbase + C::HW + 1) * C::F + c * 8), dxacc);
     }
+    SR_BWD_PRIO(0);
     const int Y = ty0 + oy, X = tx0 + ox;
     if (Y < H && X < W) {
       T* o = dx + img + ((size_t)Y * W + X) * F;
