@@ -24,6 +24,12 @@
 #else
 #define SR_RS_PRIO(p) __builtin_amdgcn_s_setprio(p)
 #endif
+#ifndef SR_RS_PRIO_A
+#define SR_RS_PRIO_A 2
+#endif
+#ifndef SR_RS_PRIO_B
+#define SR_RS_PRIO_B 2
+#endif
 
 // 16-byte chunks the staging DMA reads for lanes without pixel data: [0..7] = ones chunk (bf16 1.0, then
 // zeros), [8..15] = zeros
@@ -154,7 +160,7 @@ SR_DEV f32x16 rw_t_tile(const bf16x8 (&xb)[C::KS1], const RwA<C>& w, const float
   // a wave inside an MFMA chain goes first at the issue arbiter: the other wave of the SIMD is then the one that fills the
   // gaps with its epilogue VALU work and not the other way round (measured: two-role pipeline kernel at batch 512 89.4 -> 84.5 us,
   // the per-tile kernel at batch 32 9.40 -> 9.31 us; results unchanged)
-  SR_RS_PRIO(2);
+  SR_RS_PRIO(SR_RS_PRIO_A);
   f32x16 h = conv1_init(0);
   h = conv1_step(h, 0, 0);
   h = conv1_step(h, 0, 1);
@@ -382,7 +388,7 @@ SR_DEV f32x16 rw_b_chain(const A& a, const RwB<C>& w, MID mid, PF pf) {
 #pragma unroll
   for (int s = 0; s < AHEAD; ++s) f[s] = a.frag(s);
   f32x16 acc = zero16();
-  SR_RS_PRIO(2);
+  SR_RS_PRIO(SR_RS_PRIO_B);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int s = 0; s < KS3; ++s) {
