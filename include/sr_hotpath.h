@@ -318,6 +318,9 @@ typedef struct {
   /* optional two-part backward (sr_wdsr_net_backward_part): first block of the late half, and the rows of chan_tab /
    * bias_tab where the late parameters (body[nb_split..], tail, skip) begin */
   int nb_split, chan_split, bias_split;
+  /* sr_wdsr_net_train_step only: 1 = every parameter belongs to exactly one row of chan_tab / bias_tab, so the Adam update is
+   * applied by the weight-norm backward's launch (one launch less); 0 = separate sr_adam_step pass */
+  int adam_in_wn_bwd;
 } sr_wdsr_net_t;
 
 /* weight-norm + packing + head + NB fused blocks + fused tail.  flags: SR_NET_SAVE_ACTS keeps every block input

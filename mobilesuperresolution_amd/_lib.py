@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SR_HOTPATH_LIB_PATH (tools/ only): an explicitly named build of the same sources (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("SR_HOTPATH_LIB_PATH") or os.path.join(
     _HERE, "libsr_hotpath_dbg.so" if os.environ.get("SR_HOTPATH_DEBUG_LIB") == "1" else "libsr_hotpath.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
 
 _P, _I, _Z, _L, _F = c_void_p, c_int, c_size_t, ctypes.c_long, ctypes.c_float
@@ -90,7 +90,7 @@ class WdsrNet(ctypes.Structure):
          ("gt_sidx", _P), ("gt_dst", _P), ("n_gt", _I), ("gh_sidx", _P), ("gh_dst", _P), ("n_gh", _I),
          ("x", _P), ("acts", _P), ("grads", _P), ("out", _P), ("dout", _P), ("tsave", _P), ("dtsave", _P),
          ("hr", _P), ("loss_kind", _I), ("loss_gscale", _F), ("loss_part", _P),
-         ("nb_split", _I), ("chan_split", _I), ("bias_split", _I)])
+         ("nb_split", _I), ("chan_split", _I), ("bias_split", _I), ("adam_in_wn_bwd", _I)])
 
 
 class C3Warp(ctypes.Structure):

@@ -17,7 +17,7 @@
 #include "train_step.h"
 #include "pixel_shuffle.h"
 
-extern "C" int sr_abi_version(void) { return 7; }
+extern "C" int sr_abi_version(void) { return 8; }
 
 namespace {
 
@@ -820,7 +820,11 @@ extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int flags, sr_stream_
 // Backward in up to two parts so that the gradient of the LATE parameters (blocks [nb_split, NB), tail, skip) is final --
 // bucket-ready for a DistributedDataParallel all-reduce -- before the early half (head, blocks [0, nb_split)) runs.
 //   part 0: everything (one call);  part 1: late half;  part 2: early half (after part 1).
-extern "C" int sr_wdsr_net_backward_part(const sr_wdsr_net_t* n, int part, sr_stream_t stream) {
+namespace {
+struct FusedAdam { float* m; float* v; AdamArgs a; const float* loss_part; int n_loss; float loss_scale; float* loss_out; };
+}
+// fa != nullptr (part 0 only): the weight-norm backward also applies the Adam step (wn_bwd_adam_kernel)
+static int net_backward_part_impl(const sr_wdsr_net_t* n, int part, sr_stream_t stream, const FusedAdam* fa) {
   if (!n || !n->flat || !n->gflat || !n->dsrc || !n->x || !n->acts || !n->grads || part < 0 || part > 2) return -2;
   if (part != 2 && (n->hr ? (!n->out || !n->loss_part || (n->loss_kind != 1 && n->loss_kind != 2)) : !n->dout)) return -2;
   hipStream_t st = (hipStream_t)stream;
@@ -932,10 +936,18 @@ extern "C" int sr_wdsr_net_backward_part(const sr_wdsr_net_t* n, int part, sr_st
   const int c0 = part == 1 ? n->chan_split : 0, c1 = part == 2 ? n->chan_split : n->n_chan;
   const int d0 = part == 1 ? n->bias_split : 0, d1 = part == 2 ? n->bias_split : n->n_bias;
   const int cb = (c1 - c0 + 3) / 4, bb = (d1 - d0 + 255) / 256;
-  hipLaunchKernelGGL(wn_bwd_kernel, dim3(cb + bb), dim3(256), 0, st, n->flat, n->dsrc, n->gflat, (const int4*)n->chan_tab + c0,
-                     c1 - c0, n->bias_tab + 3 * d0, d1 - d0, cb);
+  if (fa)
+    hipLaunchKernelGGL(wn_bwd_adam_kernel, dim3(cb + bb), dim3(256), 0, st, const_cast<float*>(n->flat), n->dsrc, n->gflat, fa->m, fa->v,
+                       (const int4*)n->chan_tab + c0, c1 - c0, n->bias_tab + 3 * d0, d1 - d0, cb, fa->a, fa->loss_part, fa->n_loss,
+                       fa->loss_scale, fa->loss_out);
+  else
+    hipLaunchKernelGGL(wn_bwd_kernel, dim3(cb + bb), dim3(256), 0, st, n->flat, n->dsrc, n->gflat, (const int4*)n->chan_tab + c0,
+                       c1 - c0, n->bias_tab + 3 * d0, d1 - d0, cb);
   SR_HIP_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int sr_wdsr_net_backward_part(const sr_wdsr_net_t* n, int part, sr_stream_t stream) {
+  return net_backward_part_impl(n, part, stream, nullptr);
 }
 
 extern "C" int sr_wdsr_net_backward(const sr_wdsr_net_t* n, sr_stream_t stream) { return sr_wdsr_net_backward_part(n, 0, stream); }
@@ -1173,6 +1185,14 @@ extern "C" int sr_wdsr_net_train_step(const sr_wdsr_net_t* n, float* m, float* v
   if (!n || !n->hr || !m || !v || !a || n_params <= 0) return -2;
   int rc;
   if ((rc = sr_wdsr_net_forward(n, SR_NET_SAVE_ACTS, stream))) return rc;
+  // every parameter belongs to exactly one row of the weight-norm tables (the caller checks it: n_params == rows' elements),
+  // so the Adam update rides on the weight-norm backward; SR_TRAIN_SEPARATE_ADAM=1: the two launches
+  static const bool separate = getenv("SR_TRAIN_SEPARATE_ADAM") != nullptr;
+  if (!separate && n->adam_in_wn_bwd) {
+    const FusedAdam fa{m, v, AdamArgs{a->w_lerp, a->beta2, a->one_minus_beta2, a->bc2_sqrt, a->eps, a->neg_step_size}, n->loss_part,
+                       n->wgs_tail, loss_scale, loss_out};
+    return net_backward_part_impl(n, 0, stream, &fa);
+  }
   if ((rc = sr_wdsr_net_backward(n, stream))) return rc;
   return sr_adam_step(const_cast<float*>(n->flat), n->gflat, m, v, n_params, a, n->loss_part, n->wgs_tail, loss_scale, loss_out, stream);
 }

@@ -64,3 +64,75 @@ __global__ __launch_bounds__(64) void loss_sum_kernel(const float* __restrict__ 
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if (threadIdx.x == 0) *loss_out = s * loss_scale;
 }
+
+// Weight-norm backward and the Adam step in ONE launch (single-process training step): a wave that has just produced the
+// gradient of its channel's v row and g (or a thread its bias entry's) applies the Adam update to exactly those
+// parameters -- every parameter of the network belongs to exactly one table row, so the separate pass over the flat
+// buffer and its launch go away.  Same arithmetic as wn_bwd_kernel followed by adam_step_kernel, element for element
+// (tests/test_gpu_train_step.py: parameters bit-identical to torch.optim.Adam's); the gradient is still written out.
+SR_DEV void adam_elem(float& p, float g, float& m, float& v, const AdamArgs& a) {
+  m = __builtin_fmaf(a.w_lerp, g - m, m);
+  const float vb = v * a.beta2;
+  v = __builtin_fmaf(a.one_minus_beta2, g * g, vb);
+  const float d = __builtin_sqrtf(v) / a.bc2_sqrt + a.eps;
+  p = __builtin_fmaf(a.neg_step_size, m / d, p);
+}
+
+__global__ __launch_bounds__(256) void wn_bwd_adam_kernel(float* __restrict__ flat, const float* __restrict__ dsrc,
+                                                          float* __restrict__ gflat, float* __restrict__ em, float* __restrict__ ev,
+                                                          const int4* __restrict__ chan_tab, int n_chan,
+                                                          const int* __restrict__ bias_tab, int n_bias, int chan_blocks, AdamArgs a,
+                                                          const float* __restrict__ loss_part, int n_loss, float loss_scale,
+                                                          float* __restrict__ loss_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (loss_out && blockIdx.x == gridDim.x - 1 && threadIdx.x >= 192) {   // the last (bias) block's last wave also folds the loss
+    float s = 0.f;
+    for (int i = lane; i < n_loss; i += 64) s += loss_part[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) *loss_out = s * loss_scale;
+  }
+  if ((int)blockIdx.x < chan_blocks) {
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= n_chan) return;
+    const int4 t = chan_tab[c];
+    float* v = flat + t.x;
+    const float* dw = dsrc + t.w;
+    float ss = 0.f, dot = 0.f;
+    for (int k = lane; k < t.z; k += 64) { const float x = v[k]; ss += x * x; dot += x * dw[k]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ss += __shfl_xor(ss, o); dot += __shfl_xor(dot, o); }
+    const float n = sqrtf(ss), g = flat[t.y];
+    const float s1 = g / n, s2 = dot / ss;
+    for (int k = lane; k < t.z; k += 64) {
+      float gk = s1 * (dw[k] - v[k] * s2);
+      asm volatile("" : "+v"(gk));                  // the gradient as wn_bwd_kernel rounds it: no contraction into the Adam arithmetic
+      gflat[t.x + k] = gk;
+      float pk = v[k], mk = em[t.x + k], vk = ev[t.x + k];
+      adam_elem(pk, gk, mk, vk, a);
+      v[k] = pk; em[t.x + k] = mk; ev[t.x + k] = vk;
+    }
+    if (lane == 0) {
+      float gg = dot / n;
+      asm volatile("" : "+v"(gg));
+      gflat[t.y] = gg;
+      float pg = g, mg = em[t.y], vg = ev[t.y];
+      adam_elem(pg, gg, mg, vg, a);
+      flat[t.y] = pg; em[t.y] = mg; ev[t.y] = vg;
+    }
+  } else {
+    const int i = (blockIdx.x - chan_blocks) * 256 + threadIdx.x;
+    if (i >= n_bias) return;
+    const int pa = bias_tab[3 * i], pb = bias_tab[3 * i + 1], d = bias_tab[3 * i + 2];
+    const float gval = dsrc[d];
+    gflat[pa] = gval;
+    { float pp = flat[pa], mm = em[pa], vv = ev[pa]; adam_elem(pp, gval, mm, vv, a); flat[pa] = pp; em[pa] = mm; ev[pa] = vv; }
+    if (pb >= 0) {
+      gflat[pb] = gval;
+      float pp = flat[pb], mm = em[pb], vv = ev[pb];
+      adam_elem(pp, gval, mm, vv, a);
+      flat[pb] = pp; em[pb] = mm; ev[pb] = vv;
+    }
+  }
+}
+

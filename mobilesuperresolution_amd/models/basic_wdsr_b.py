@@ -90,6 +90,17 @@ class _DeviceState:
             setattr(n, k + "_dst", self.g[k][1].data_ptr())
             setattr(n, "n_" + k, self.g[k][0].numel())
         n.loss_part = self.loss_part.data_ptr()
+        # the Adam update may ride on the weight-norm backward if its table rows cover every parameter exactly once
+        ct, bt = lay.chan_tab, lay.bias_tab
+        cover = np.zeros(int(model.flat.numel()), dtype=np.int32)
+        for v_off, g_off, K, _dst in ct:
+            cover[v_off:v_off + K] += 1
+            cover[g_off] += 1
+        for a_, b_, _d in bt:
+            cover[a_] += 1
+            if b_ >= 0:
+                cover[b_] += 1
+        n.adam_in_wn_bwd = int(bool((cover == 1).all()))
         if model.nb_split:
             _, n.chan_split, n.bias_split = lay.split_at(model.nb_split)
             n.nb_split = model.nb_split
