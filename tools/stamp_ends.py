@@ -1,5 +1,6 @@
 """Diagnostic: per-phase timeline of sr_tail_wgrad from in-kernel stamps (C2 shape)."""
 import os, sys
+os.environ["SR_HOTPATH_DEBUG_LIB"] = "1"          # the diagnostic build (python -m mobilesuperresolution_amd.build --debug)
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench as B

@@ -1,5 +1,6 @@
 """Diagnostic: per-phase timeline of the block weight-gradient kernels from in-kernel stamps."""
 import os, sys
+os.environ["SR_HOTPATH_DEBUG_LIB"] = "1"          # the diagnostic build (python -m mobilesuperresolution_amd.build --debug)
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mobilesuperresolution_amd import _lib as L, hotpath as HP
