@@ -376,9 +376,9 @@ int sr_probe_launch_floor(void* out, int gx, int gy, int threads, int lds_bytes,
 int sr_probe_launch_floor_graph(void* out, int gx, int gy, int threads, int lds_bytes, int reps, int iters,
                                 float* us_per_launch, float* host_us_per_graph /* may be NULL */);
 /* Debug: in the diagnostic build (libsr_hotpath_dbg.so, `python -m mobilesuperresolution_amd.build --debug`) the
- * instrumented kernels write s_memrealtime stamps to buf[workgroup][16 waves][16] (NULL = off).  The product
- * library contains no stamp code and returns -1. */
-int sr_debug_set_stamps(void* buf);
+ * instrumented kernels write s_memrealtime stamps to buf[n_workgroups][16 waves][16 stamps][2] u64 (NULL = off); workgroups
+ * beyond n_workgroups do not stamp.  The product library contains no stamp code and returns -1. */
+int sr_debug_set_stamps(void* buf, long n_workgroups);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@
 #include "train_step.h"
 #include "pixel_shuffle.h"
 
-extern "C" int sr_abi_version(void) { return 8; }
+extern "C" int sr_abi_version(void) { return 9; }
 
 namespace {
 
@@ -1320,14 +1320,18 @@ extern "C" int sr_probe_launch_floor_graph(void* out, int gx, int gy, int thread
   return rc;
 }
 
-// debug: route the in-kernel time stamps of the diagnostic build to `buf` ([workgroup][16 waves][16] u64; NULL = off).
+// debug: route the in-kernel time stamps of the diagnostic build to `buf` ([n_workgroups][16 waves][16 stamps][2] u64; NULL = off).
+// Workgroups beyond n_workgroups do not stamp (a stamped launch with a larger grid must not write past the buffer).
 // The product library carries no stamp code: there the call reports "unsupported".
-extern "C" int sr_debug_set_stamps(void* buf) {
+extern "C" int sr_debug_set_stamps(void* buf, long n_workgroups) {
 #ifdef SR_DEBUG_STAMPS
+  if (buf && n_workgroups <= 0) return -2;
   unsigned long long* p = (unsigned long long*)buf;
+  const unsigned long long n = buf ? (unsigned long long)n_workgroups : 0ull;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_sr_stamp_wgs), &n, sizeof(n)) != hipSuccess) return -3;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_sr_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -3;
 #else
-  (void)buf;
+  (void)buf; (void)n_workgroups;
   return -1;
 #endif
 }

@@ -32,9 +32,11 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 // lane 0 of every wave: the pair gives both the wall time of a phase and the clock the chip held during it.
 #ifdef SR_DEBUG_STAMPS
 __device__ unsigned long long* g_sr_stamps = nullptr;
+__device__ unsigned long long g_sr_stamp_wgs = 0;      // workgroups the buffer has room for: launches with more do not stamp past it
 #define SR_STAMP_DECL int stamp_i_ = 0
-#define SR_STAMP() do { unsigned long long* sp_ = g_sr_stamps; if (sp_ && (threadIdx.x & 63) == 0 && stamp_i_ < 16 && (threadIdx.x >> 6) < 16) { \
-    unsigned long long* q_ = sp_ + ((((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (threadIdx.x >> 6)) * 16 + stamp_i_) * 2; \
+#define SR_STAMP() do { unsigned long long* sp_ = g_sr_stamps; const size_t wg_ = (size_t)blockIdx.y * gridDim.x + blockIdx.x; \
+  if (sp_ && wg_ < g_sr_stamp_wgs && (threadIdx.x & 63) == 0 && stamp_i_ < 16 && (threadIdx.x >> 6) < 16) { \
+    unsigned long long* q_ = sp_ + ((wg_ * 16 + (threadIdx.x >> 6)) * 16 + stamp_i_) * 2; \
     q_[0] = __builtin_amdgcn_s_memrealtime(); q_[1] = __builtin_amdgcn_s_memtime(); } ++stamp_i_; } while (0)
 #else
 #define SR_STAMP_DECL do {} while (0)

@@ -31,11 +31,11 @@ def run():
 for it in range(5):
     run()
 torch.cuda.synchronize()
-L.check(lib.sr_debug_set_stamps(st.data_ptr()), "set")
+L.check(lib.sr_debug_set_stamps(st.data_ptr(), nwg), "set")
 for it in range(3):
     run()
 torch.cuda.synchronize()
-L.check(lib.sr_debug_set_stamps(None), "unset")
+L.check(lib.sr_debug_set_stamps(None, 0), "unset")
 raw = st.cpu().numpy().reshape(nwg, 16, 16, 2).astype(np.float64)
 s = raw[..., 0] * 10.0                                                    # ns (100 MHz)
 cyc = raw[..., 1]

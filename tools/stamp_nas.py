@@ -23,11 +23,11 @@ def run():
 for it in range(5):
     run()
 torch.cuda.synchronize()
-L.check(lib.sr_debug_set_stamps(st.data_ptr()), "set")
+L.check(lib.sr_debug_set_stamps(st.data_ptr(), wgs), "set")
 for it in range(3):
     run()
 torch.cuda.synchronize()
-L.check(lib.sr_debug_set_stamps(None), "unset")
+L.check(lib.sr_debug_set_stamps(None, 0), "unset")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for it in range(20):

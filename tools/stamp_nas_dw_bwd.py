@@ -16,10 +16,10 @@ def run():
     L.check(lib.sr_nas_dw_bwd(yin.data_ptr(), GZ.data_ptr(), gy.data_ptr(), gyin.data_ptr(), dwp.data_ptr(), part.data_ptr(), wgs, n, 48, 48, f, 1, L.stream_ptr()), "dw_bwd")
 for it in range(5): run()
 torch.cuda.synchronize()
-L.check(lib.sr_debug_set_stamps(st.data_ptr()), "set")
+L.check(lib.sr_debug_set_stamps(st.data_ptr(), wgs), "set")
 for it in range(3): run()
 torch.cuda.synchronize()
-L.check(lib.sr_debug_set_stamps(None), "unset")
+L.check(lib.sr_debug_set_stamps(None, 0), "unset")
 raw = st.cpu().numpy().reshape(wgs, 16, 16, 2).astype(np.float64)
 s = raw[..., 0] * 10.0
 nst = int((s[0, 0] > 0).sum()); nw = int((s[0, :, 0] > 0).sum())
