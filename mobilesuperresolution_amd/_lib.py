@@ -142,6 +142,10 @@ def lib():
             raise HotpathError(
                 f"{LIB_PATH} not found: build it with `python -m mobilesuperresolution_amd.build` "
                 "(the SR hot path has no CPU / ATen fallback)")
+        if os.environ.get("SR_HOTPATH_LIB_PATH") or os.environ.get("SR_HOTPATH_DEBUG_LIB") == "1":
+            import warnings
+            warnings.warn(f"SR hot path: loading a NON-DEFAULT library ({LIB_PATH}) because SR_HOTPATH_LIB_PATH / "
+                          "SR_HOTPATH_DEBUG_LIB is set (meant for tools/ only)", RuntimeWarning, stacklevel=2)
         l = ctypes.CDLL(LIB_PATH)
         _declare(l)
         if l.sr_abi_version() != ABI_VERSION:

@@ -2,7 +2,7 @@
 // ImageSuperResolutionDataset._sample_patch (crop at row x, column y; the HR crop at scale times that),
 // _augment (flip rows, flip columns, swap the two axes -- in that order) and torchvision's to_tensor (HWC uint8 ->
 // CHW float32 / 255), datasets/_isr.py:68-121.  The draws (image, x, y, three coin flips) stay on the host, in the
-// reference's own RNG call order; one 32-byte record per patch tells the kernel what to cut.
+// reference's own RNG call order; one 40-byte record per patch tells the kernel what to cut.
 #pragma once
 #include "sr_common.h"
 

@@ -280,7 +280,12 @@ class BASIC_MODEL(nn.Module):
         net.dtsave = None
         # opt-in (`model.assume_static_weights = True`): repeated inference with unchanged parameters re-uses the packed
         # weights of the previous call.  Off by default: an in-place write through `.data` does not bump `_version`.
-        key = (flat.data_ptr(), flat._version)
+        # Two-segment mode: the optimizer steps `flat_lo` / `flat_hi`, whose version counters are their own (`p.data = view`
+        # shares storage, not the counter): the master's `_version` never moves, so the key is built from the segments.
+        if self.grad_segments == 2:
+            key = (flat.data_ptr(), self.flat_lo._version, self.flat_hi._version)
+        else:
+            key = (flat.data_ptr(), flat._version)
         static = getattr(self, "assume_static_weights", False) and not save_acts and st.packed_key == key
         flags = (1 if save_acts else 0) | (2 if static else 0)
         with torch.cuda.device(x.device):

@@ -43,6 +43,25 @@ def _const(device: torch.device, values: tuple) -> torch.Tensor:
     return torch.tensor(values, dtype=torch.float32, device=device)
 
 
+def _on_tensor_device(fn):
+    """Run an autograd.Function's forward / backward with the FIRST CUDA tensor argument's device current: the kernels take raw
+    pointers and `L.stream_ptr()` returns the current device's stream, so a block used standalone on a GPU that is not the
+    current one would otherwise launch on the wrong device's stream (NAS_MODEL.forward holds the same guard)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(ctx, *args):
+        dev = next((a.device for a in args if isinstance(a, torch.Tensor) and a.is_cuda), None)
+        if dev is None:
+            dev = next((t.device for t in getattr(ctx, "saved_tensors", ()) if t.is_cuda), None)
+        if dev is None:
+            return fn(ctx, *args)
+        with torch.cuda.device(dev):
+            return fn(ctx, *args)
+    return wrapped
+
+
+
 def _hot_dtype(params) -> torch.dtype:
     name = getattr(params, "hot_dtype", None) or os.environ.get("SR_HOT_DTYPE", "fp32")
     return name if isinstance(name, torch.dtype) else _DTYPES[str(name).lower()]
@@ -108,6 +127,7 @@ class _NasBlockFunction(torch.autograd.Function):
     """y = mg*yin + beta2 * ms * sum_k p_k relu(pw_k(relu(dw_k(mg*ms*yin)))) on csrc/nas_block.h"""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, yin, wdw3, wdw5, wdw7, bdw, wpw, bpw, mg, ms, p, beta):
         n, h, w, f = yin.shape
         dev, dt = yin.device, yin.dtype
@@ -131,6 +151,7 @@ class _NasBlockFunction(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, gy):
         yin, V, dwp, frags, tabs, scal, mg, ms, p, beta = ctx.saved_tensors
         n, h, w, f = yin.shape
@@ -175,6 +196,7 @@ class _NasBodyFunction(torch.autograd.Function):
     MS (nb, F), P (nb, 3), BETA (nb, 2)."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, y0, WDW3, WDW5, WDW7, BDW, WPW, BPW, mg, MS, P, BETA):
         n, h, w, f = y0.shape
         nb = WDW3.shape[0]
@@ -203,6 +225,7 @@ class _NasBodyFunction(torch.autograd.Function):
         return ys[nb]
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, gy):
         ys, V, dwp, frags, tabs, scal, MS, P, BETA = ctx.saved_tensors
         nb, n, h, w, f = V.shape[0], V.shape[2], V.shape[3], V.shape[4], V.shape[5]
@@ -270,6 +293,7 @@ class _NasBodyNative(torch.autograd.Function):
     Inputs: flat (the body parameter), mg (F,), MS (nb, F), P (nb, 3), BETA (nb, 2), layout / frozen of the model."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, y0, flat, mg, MS, P_, BETA, layout, frozen, src_pre=None, scal_pre=None, nb_total=None, blocks=None):
         n, h, w, f = y0.shape
         nb = MS.shape[0]
@@ -311,6 +335,7 @@ class _NasBodyNative(torch.autograd.Function):
         return ys[nb]
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, gy):
         ys, V, dwp, frags, tabs, scal, MS, P_, BETA, flat = ctx.saved_tensors
         nb, n, h, w, f = V.shape[0], V.shape[2], V.shape[3], V.shape[4], V.shape[5]
@@ -805,10 +830,11 @@ class NAS_MODEL(nn.Module):
         # per-block kernel scalars softmax(alpha) | gate2
         src = torch.empty((nb, off["size"]), dtype=torch.float32, device=fl.device)
         scal = torch.empty((nb, 4), dtype=torch.float32, device=fl.device)
-        L.launch("sr_nas_scalars", L.lib().sr_nas_scalars, self.mask.weight.detach().data_ptr(),
-                 self.kind("split.weight", fl).data_ptr(), self.kind("alpha", fl).data_ptr(), self.kind("alpha1", fl).data_ptr(),
-                 self.kind("alpha2", fl).data_ptr(), nb, f, out.data_ptr(), src.data_ptr(), src.stride(0), off["mg"], scal.data_ptr(),
-                 L.stream_ptr())
+        with torch.cuda.device(fl.device):
+            L.launch("sr_nas_scalars", L.lib().sr_nas_scalars, self.mask.weight.detach().data_ptr(),
+                     self.kind("split.weight", fl).data_ptr(), self.kind("alpha", fl).data_ptr(), self.kind("alpha1", fl).data_ptr(),
+                     self.kind("alpha2", fl).data_ptr(), nb, f, out.data_ptr(), src.data_ptr(), src.stride(0), off["mg"],
+                     scal.data_ptr(), L.stream_ptr(fl.device))
         o = f + 1
         return dict(mask_hard=out[:f].view(f, 1, 1, 1), ms_hard=out[o:o + nb * f].view(nb, f),
                     speed_curr=out[o + nb * (f + 1):o + nb * (f + 2)], gates=out[o + nb * (f + 2):].view(nb, 2), src=src, scal=scal)

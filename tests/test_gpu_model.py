@@ -310,6 +310,34 @@ def test_static_weights_inference_skips_prep_and_matches():
     assert torch.equal(c, d) and not torch.equal(c, ref)
 
 
+@pytest.mark.gpu
+def test_static_weights_two_segment_mode_repacks_after_optimizer_step():
+    """with hot_grad_segments = 2 the optimizer steps flat_lo / flat_hi, whose version counters are not the
+    master buffer's: the packed-weights key must follow the segments, or an eval forward after a step would run on the
+    pre-step weights.  Checked against the one-parameter model carrying the same (stepped) weights."""
+    torch.manual_seed(10)
+    m2 = _model(_ns(num_blocks=2, hot_dtype="bf16", hot_grad_segments=2))
+    m1 = _model(_ns(num_blocks=2, hot_dtype="bf16"))
+    x = torch.rand(2, 3, 20, 28, device="cuda")
+    hr = torch.rand(2, 3, 80, 112, device="cuda")
+    m2.assume_static_weights = True
+    m2.eval()
+    with torch.no_grad():
+        before = m2(x)
+        assert torch.equal(m2(x), before)                   # (the shortcut is taken here)
+    m2.train()
+    opt = torch.optim.Adam(m2.parameters(), lr=1e-2)
+    torch.nn.functional.l1_loss(m2(x), hr).backward()
+    opt.step()
+    m2.eval()
+    m1.load_state_dict(m2.state_dict(), strict=True)
+    m1.eval()
+    with torch.no_grad():
+        after, ref = m2(x), m1(x)
+    assert not torch.equal(after, before)
+    assert torch.equal(after, ref)
+
+
 def test_large_batch_inference_takes_the_persistent_launches_and_equals_small_batches():
     """eval mode, bf16, 130 patches of 48x48 = 1040 tiles: sr_wdsr_net_forward runs the persistent two-block launches; the
     result equals the same patches pushed through in batches of 10 (per-tile launches), bit for bit"""
