@@ -9,7 +9,8 @@ never travels to the GPU box):
 The fixtures are data (inputs, parameters, expected outputs/gradients); no
 reference source is copied.  tests/test_oracle_golden.py pins oracle/wdsr_oracle.py
 against them, and the -m gpu parity tests compare the HIP path with the same
-files.  Fixture ids follow SURVEY.md section 8(c): G1..G9.
+files.  Fixture ids follow SURVEY.md section 8(c): G1..G9, then G10..G14 (whole NAS model, video models, Set5-shaped
+images, the dataset item path).
 """
 import argparse
 import hashlib
@@ -378,6 +379,120 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from set5_like import SET5_SHAPES, set5_like_hr  # noqa: E402
 
 
+def _absent_third_party_stubs():
+    """sys.modules stand-ins for THIRD-PARTY packages that are not installed here (skimage, mmedit, torchvision, h5py-free
+    paths): they carry no arithmetic of the reference.  `torchvision.transforms.functional.to_tensor` is restated for the
+    one input kind the dataset path feeds it (H x W x C uint8 ndarray -> C x H x W float32 / 255: torchvision's documented
+    behaviour); everything else raises if touched."""
+    def mod(name, **attrs):
+        m = sys.modules.get(name)
+        if m is None:
+            m = types.ModuleType(name)
+            sys.modules[name] = m
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        return m
+
+    def absent(*a, **k):
+        raise RuntimeError("third-party function absent in this container (stub)")
+
+    def to_tensor(pic):
+        a = np.asarray(pic)
+        assert a.dtype == np.uint8 and a.ndim == 3
+        return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1))).to(torch.float32).div(255)
+
+    mod("skimage", img_as_float=absent, img_as_ubyte=absent)
+    mod("skimage.io", imread=absent)
+    mod("skimage.metrics", structural_similarity=absent)
+    mod("mmedit")
+    mod("mmedit.core")
+    mod("mmedit.core.evaluation")
+    mod("mmedit.core.evaluation.metrics", psnr=absent, ssim=absent)
+    tf = mod("torchvision.transforms.functional", to_tensor=to_tensor)
+    tt = mod("torchvision.transforms", functional=tf)
+    mod("torchvision", transforms=tt)
+
+
+def _reference_metrics():
+    """the reference's own common/metrics.py (psnr, psnr_y), imported with skimage / mmedit stubbed"""
+    _absent_third_party_stubs()
+    import importlib
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    return importlib.import_module("common.metrics")
+
+
+def g9_metrics():
+    """G9: common/metrics.py:10-38 itself on the hand cases of tests/test_oracle_golden.py and on random images (batch > 1:
+    the SUM over the batch; 1-channel input: no luma filter; shave 0 / 4 / 10)."""
+    M = _reference_metrics()
+    g = torch.Generator().manual_seed(90)
+    d = {}
+    cases = []
+    for k, (n, c, h, w, shave) in enumerate([(1, 3, 40, 52, 4), (3, 3, 33, 47, 10), (2, 1, 24, 24, 4), (2, 3, 20, 28, 0)]):
+        hr = torch.rand(n, c, h, w, generator=g)
+        sr = (hr + 0.05 * torch.randn(n, c, h, w, generator=g)) * 1.1 - 0.03          # leaves [0,1] here and there: clamps matter
+        cases.append((k, sr, hr, shave))
+    for k, sr, hr, shave in cases:
+        d[f"sr_{k}"], d[f"hr_{k}"], d[f"shave_{k}"] = _np(sr), _np(hr), np.int64(shave)
+        d[f"psnr_{k}"] = np.float64(M.psnr(sr, hr, shave=shave).item())
+        d[f"psnr_y_{k}"] = np.float64(M.psnr_y(sr, hr, shave=shave).item())
+        print(f"G9 case {k}: psnr {d[f'psnr_{k}']:.5f} psnr_y {d[f'psnr_y_{k}']:.5f}")
+    d["n_cases"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(OUT, "g9_metrics.npz"), **d)
+
+
+def g14_patches():
+    """G14: the reference's own training-item path, datasets/_isr.py:56-121 -- `ImageSuperResolutionDataset.__getitem__` in
+    TRAIN mode (`_load_item` through PIL on PNG files written here, `_sample_patch`, `_augment`, `to_tensor`) under a seeded
+    `random`.  Stored: the decoded images, the parameters, every item's LR / HR patch as uint8 (exact: to_tensor only divides
+    by 255) and `random.random()` drawn right after the last item (pins the number of draws)."""
+    import importlib
+    import random
+    import tempfile
+    from PIL import Image
+    _absent_third_party_stubs()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    isr = importlib.import_module("datasets._isr")
+    modes = importlib.import_module("common.modes")
+    d = {}
+    cfgs = [(4, 24, 0, 3), (2, 32, 4, 1), (3, 17, 2, 2)]
+    d["cfgs"] = np.array(cfgs, dtype=np.int64)
+    with tempfile.TemporaryDirectory() as tmp:
+        for ci, (scale, P, ignored, num_patches) in enumerate(cfgs):
+            g = np.random.default_rng(140 + ci)
+            lr_files, hr_files = [], []
+            n_img = 4
+            for k in range(n_img):
+                h, w = int(g.integers(40, 90)), int(g.integers(40, 90))
+                lr = g.integers(0, 256, (h, w, 3), dtype=np.uint8)
+                hr = g.integers(0, 256, (h * scale + (k % 2), w * scale + (k % 3), 3), dtype=np.uint8)
+                lp, hp = os.path.join(tmp, f"c{ci}_lr{k}.png"), os.path.join(tmp, f"c{ci}_hr{k}.png")
+                Image.fromarray(lr).save(lp)
+                Image.fromarray(hr).save(hp)
+                lr_files.append((f"{k}.png", lp))
+                hr_files.append((f"{k}.png", hp))
+                d[f"c{ci}_lr{k}"], d[f"c{ci}_hr{k}"] = lr, hr
+            params = argparse.Namespace(scale=scale, lr_patch_size=P, ignored_boundary_size=ignored, num_patches=num_patches)
+            ds = isr.ImageSuperResolutionDataset(modes.TRAIN, params, lr_files, hr_files)
+            idx = list(range(len(ds))) * (24 // num_patches)
+            random.seed(1400 + ci)
+            lrs, hrs = [], []
+            for i in idx:
+                a, b = ds[i]
+                lrs.append((a * 255).round().to(torch.uint8).numpy())
+                hrs.append((b * 255).round().to(torch.uint8).numpy())
+                assert torch.equal(torch.from_numpy(lrs[-1]).float().div(255), a)
+            d[f"c{ci}_idx"] = np.array(idx, dtype=np.int64)
+            d[f"c{ci}_seed"] = np.int64(1400 + ci)
+            d[f"c{ci}_lr_items"], d[f"c{ci}_hr_items"] = np.stack(lrs), np.stack(hrs)
+            d[f"c{ci}_next_random"] = np.float64(random.random())
+            d[f"c{ci}_n_img"] = np.int64(n_img)
+            print(f"G14 cfg {ci} (scale {scale}, P {P}, ignored {ignored}, num_patches {num_patches}): {len(idx)} items")
+    np.savez_compressed(os.path.join(OUT, "g14_patches.npz"), **d)
+
+
 def g13_set5_shaped(BASIC_MODEL):
     """Set5 is absent offline, so PSNR parity is pinned on five synthetic images with Set5's shapes.  LR is
     made by the reference's own numpy MATLAB-imresize clone (third_party/matlab_imresize/imresize.py:104-136) after
@@ -390,8 +505,7 @@ def g13_set5_shaped(BASIC_MODEL):
     stored), the x4 weights from theirs (checksum stored)."""
     sys.path.insert(0, os.path.join(REF, "third_party", "matlab_imresize"))
     from imresize import imresize
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    import wdsr_oracle as O
+    M = _reference_metrics()                                 # the reference's own common/metrics.py
     nets = {}
     m2 = BASIC_MODEL(_params(num_blocks=8, num_residual_units=24, scale=2)).eval()
     m2.load_state_dict(torch.load(os.path.join(REF, "models", "pretrained_weights", "wdsr_b_x2_8_24.pt"), map_location="cpu",
@@ -415,8 +529,8 @@ def g13_set5_shaped(BASIC_MODEL):
             d["sr_sample_" + k] = _np(sr[..., ::4, ::4])
             d["sr_mean_" + k] = np.float64(sr.double().mean().item())
             d["sr_abs_" + k] = np.float64(sr.double().abs().mean().item())
-            d["psnr_" + k] = np.float64(O.psnr(sr, hr[None], shave=r + 6).item())         # utils/estimate.py:123: shave = scale + 6
-            d["psnr_y_" + k] = np.float64(O.psnr_y(sr, hr[None], shave=r).item())         # :125: shave = scale
+            d["psnr_" + k] = np.float64(M.psnr(sr, hr[None], shave=r + 6).item())         # utils/estimate.py:123: shave = scale + 6
+            d["psnr_y_" + k] = np.float64(M.psnr_y(sr, hr[None], shave=r).item())         # :125: shave = scale
             if tag == "x2":
                 d[f"hr_sum_{i}"] = np.float64(hr.double().sum().item())
             print(f"G13 {tag} image {i} {tuple(hr.shape)}: psnr {d['psnr_' + k]:.4f} psnr_y {d['psnr_y_' + k]:.4f}")
@@ -431,16 +545,14 @@ def main():
     from models.basic_wdsr_b import BASIC_MODEL, Block
     import models.ops as ops
     import models.wdsr_b as wdsr_b
-    g1_model(BASIC_MODEL)
-    g2_block(Block)
-    g3_pretrained(BASIC_MODEL)
-    g4_pixel_shuffle()
-    g5_rounding(ops)
-    g6_split_block(wdsr_b)
-    g7_g8_vsr()
-    g10_nas_model()
-    g11_g12_video_models()
-    g13_set5_shaped(BASIC_MODEL)
+    gens = {"g1": lambda: g1_model(BASIC_MODEL), "g2": lambda: g2_block(Block), "g3": lambda: g3_pretrained(BASIC_MODEL),
+            "g4": g4_pixel_shuffle, "g5": lambda: g5_rounding(ops), "g6": lambda: g6_split_block(wdsr_b), "g7": g7_g8_vsr,
+            "g10": g10_nas_model, "g11": g11_g12_video_models, "g13": lambda: g13_set5_shaped(BASIC_MODEL), "g9": g9_metrics,
+            "g14": g14_patches}
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]          # e.g. `make_golden.py g9 g14`: just those fixtures
+    for name, fn in gens.items():
+        if not only or name in only:
+            fn()
 
 
 if __name__ == "__main__":

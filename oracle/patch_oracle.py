@@ -1,7 +1,9 @@
 """TEST INFRASTRUCTURE (oracle): CPU restatement of the reference's training-item path, datasets/_isr.py:68-121, for the
 parity tests of mobilesuperresolution_amd.datasets.  numpy only; `to_tensor` restates torchvision's for uint8 HWC input
-(permute to CHW, float32, divide by 255).  Pinned by construction against the reference text; the reference's own
-dataset class needs torchvision / PIL files and is not importable here ("parity unpinned" beyond this restatement)."""
+(permute to CHW, float32, divide by 255).  PINNED since round 3: oracle/make_golden.py imports the reference's own
+ImageSuperResolutionDataset (skimage / torchvision stubbed: third-party, absent here), runs __getitem__ on PNG files under a
+seeded `random` and writes fixture G14; tests/test_oracle_golden.py::test_g14_* holds this file to it item for item.
+(`to_tensor` itself is torchvision's: restated in the stub, the one unpinned step -- a division by 255.)"""
 import numpy as np
 
 

@@ -52,6 +52,16 @@ def test_device_psnr_hand_cases_g9():
     assert math.isnan(float(psnr(hr + e, hr, shave=8)))                                  # everything shaved: mean of nothing
 
 
+def test_device_psnr_matches_reference_metrics_g9(golden_dir):
+    """sr_psnr against values written by the reference's own common/metrics.py (fixture G9, oracle/make_golden.py)"""
+    from mobilesuperresolution_amd.metrics import psnr, psnr_y
+    z = np.load(os.path.join(golden_dir, "g9_metrics.npz"))
+    for k in range(int(z["n_cases"])):
+        sr, hr, shave = torch.from_numpy(z[f"sr_{k}"]).cuda(), torch.from_numpy(z[f"hr_{k}"]).cuda(), int(z[f"shave_{k}"])
+        assert float(psnr(sr, hr, shave=shave)) == pytest.approx(float(z[f"psnr_{k}"]), abs=1e-3), k
+        assert float(psnr_y(sr, hr, shave=shave)) == pytest.approx(float(z[f"psnr_y_{k}"]), abs=1e-3), k
+
+
 @pytest.mark.parametrize("shape,shave", [((3, 3, 37, 53), 4), ((1, 3, 192, 192), 10), ((2, 1, 20, 24), 2), ((2, 5, 3, 24, 28), 4),
                                          ((1, 3, 9, 9), 0)])
 def test_device_psnr_matches_oracle(shape, shave):

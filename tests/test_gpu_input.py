@@ -1,4 +1,6 @@
-"""f3: training patches cut on device (csrc/patches.h) against the CPU restatement of datasets/_isr.py:68-121, draw for draw."""
+"""f3: training patches cut on device (csrc/patches.h) against items of the reference's own dataset class (fixture G14, written by
+oracle/make_golden.py from datasets/_isr.py:56-121) and against the CPU restatement, draw for draw."""
+import os
 import random
 
 import numpy as np
@@ -39,6 +41,25 @@ def test_device_patches_equal_reference_items_draw_for_draw(scale, P, ignored, n
         assert torch.equal(lr[b].cpu(), torch.from_numpy(el)), (b, i)
         assert torch.equal(hr[b].cpu(), torch.from_numpy(eh)), (b, i)
     assert seen == set(range(8))
+
+
+def test_device_patches_equal_reference_dataset_items_g14(golden_dir):
+    """G14: every item the reference's ImageSuperResolutionDataset.__getitem__ produced under a seeded `random` comes out of
+    DevicePatchCache.batch bit for bit, and the RNG has made the same number of draws afterwards"""
+    from mobilesuperresolution_amd.datasets import DevicePatchCache
+    z = np.load(os.path.join(golden_dir, "g14_patches.npz"))
+    for ci, (scale, P, ignored, num_patches) in enumerate(z["cfgs"].tolist()):
+        n_img = int(z[f"c{ci}_n_img"])
+        lrs = [z[f"c{ci}_lr{k}"] for k in range(n_img)]
+        hrs = [z[f"c{ci}_hr{k}"] for k in range(n_img)]
+        ds = DevicePatchCache(lrs, hrs, P, scale, ignored, num_patches)
+        rng = random.Random(int(z[f"c{ci}_seed"]))
+        lr, hr = ds.batch(z[f"c{ci}_idx"].tolist(), rng)
+        exp_lr = torch.from_numpy(z[f"c{ci}_lr_items"]).float().div(255)
+        exp_hr = torch.from_numpy(z[f"c{ci}_hr_items"]).float().div(255)
+        assert torch.equal(lr.cpu(), exp_lr), ci
+        assert torch.equal(hr.cpu(), exp_hr), ci
+        assert rng.random() == float(z[f"c{ci}_next_random"])
 
 
 def test_device_cache_consumes_the_rng_like_the_reference():

@@ -146,8 +146,7 @@ def test_g8_flow_warp(golden_dir):
 
 
 def test_g9_psnr_hand_cases():
-    """common/metrics.py is not importable (skimage/mmedit absent): the
-    restatement is pinned by hand-computed cases."""
+    """hand-computed cases; the reference's own values: test_g9_psnr_matches_reference_metrics"""
     hr = torch.full((1, 3, 16, 16), 0.5)
     sr = hr + 1.0 / 255.0
     # quantise: (0.5+1/255)*255 = 128.5 -> round-half-even 128 -> 128/255; diff = 128/255-0.5 = 0.5/255
@@ -163,6 +162,35 @@ def test_g9_psnr_hand_cases():
     assert float(O.psnr_y(torch.cat([hr + e] * 3), torch.cat([hr] * 3), shave=2)) == pytest.approx(3 * exp_y, abs=3e-3)
     # clamp to [0,1] before the difference
     assert float(O.psnr_y(torch.full_like(hr, 1.5), torch.ones_like(hr) - e, shave=0)) == pytest.approx(exp_y, abs=1e-3)
+
+
+def test_g9_psnr_matches_reference_metrics(golden_dir):
+    """G9 (round 3): psnr / psnr_y values written by the reference's OWN common/metrics.py (imported by
+    oracle/make_golden.py with skimage / mmedit stubbed) pin the oracle's restatement: clamps, batch sum, 1-channel input,
+    shave 0 / 4 / 10."""
+    d = _load(golden_dir, "g9_metrics.npz")
+    for k in range(int(d["n_cases"])):
+        sr, hr, shave = d[f"sr_{k}"], d[f"hr_{k}"], int(d[f"shave_{k}"])
+        assert float(O.psnr(sr, hr, shave=shave)) == pytest.approx(float(d[f"psnr_{k}"]), abs=1e-4), k
+        assert float(O.psnr_y(sr, hr, shave=shave)) == pytest.approx(float(d[f"psnr_y_{k}"]), abs=1e-4), k
+
+
+def test_g14_patch_oracle_matches_reference_dataset_items(golden_dir):
+    """G14: items of the reference's own ImageSuperResolutionDataset.__getitem__ (TRAIN; datasets/_isr.py:56-121) under a
+    seeded `random` pin oracle/patch_oracle.py: crop origins, flip / swap order, HR crop at scale, number of RNG draws."""
+    import random
+    from oracle import patch_oracle as PO
+    z = np.load(os.path.join(golden_dir, "g14_patches.npz"))
+    for ci, (scale, P, ignored, num_patches) in enumerate(z["cfgs"].tolist()):
+        n_img = int(z[f"c{ci}_n_img"])
+        lrs = [z[f"c{ci}_lr{k}"] for k in range(n_img)]
+        hrs = [z[f"c{ci}_hr{k}"] for k in range(n_img)]
+        rng = random.Random(int(z[f"c{ci}_seed"]))
+        for b, i in enumerate(z[f"c{ci}_idx"].tolist()):
+            lr, hr = PO.train_item(lrs, hrs, i, P, scale, ignored, num_patches, rng)
+            assert np.array_equal(lr, z[f"c{ci}_lr_items"][b].astype(np.float32) / np.float32(255)), (ci, b)
+            assert np.array_equal(hr, z[f"c{ci}_hr_items"][b].astype(np.float32) / np.float32(255)), (ci, b)
+        assert rng.random() == float(z[f"c{ci}_next_random"])
 
 
 # ---- G10: the whole reference NAS_MODEL pins the oracle's model-level glue ----
