@@ -457,15 +457,15 @@ def g14_patches():
     isr = importlib.import_module("datasets._isr")
     modes = importlib.import_module("common.modes")
     d = {}
-    cfgs = [(4, 24, 0, 3), (2, 32, 4, 1), (3, 17, 2, 2)]
+    cfgs = [(4, 12, 0, 3), (2, 16, 4, 1), (3, 11, 2, 2)]
     d["cfgs"] = np.array(cfgs, dtype=np.int64)
     with tempfile.TemporaryDirectory() as tmp:
         for ci, (scale, P, ignored, num_patches) in enumerate(cfgs):
             g = np.random.default_rng(140 + ci)
             lr_files, hr_files = [], []
-            n_img = 4
+            n_img = 3
             for k in range(n_img):
-                h, w = int(g.integers(40, 90)), int(g.integers(40, 90))
+                h, w = int(g.integers(40, 64)), int(g.integers(40, 64))
                 lr = g.integers(0, 256, (h, w, 3), dtype=np.uint8)
                 hr = g.integers(0, 256, (h * scale + (k % 2), w * scale + (k % 3), 3), dtype=np.uint8)
                 lp, hp = os.path.join(tmp, f"c{ci}_lr{k}.png"), os.path.join(tmp, f"c{ci}_hr{k}.png")
@@ -476,7 +476,7 @@ def g14_patches():
                 d[f"c{ci}_lr{k}"], d[f"c{ci}_hr{k}"] = lr, hr
             params = argparse.Namespace(scale=scale, lr_patch_size=P, ignored_boundary_size=ignored, num_patches=num_patches)
             ds = isr.ImageSuperResolutionDataset(modes.TRAIN, params, lr_files, hr_files)
-            idx = list(range(len(ds))) * (24 // num_patches)
+            idx = (list(range(len(ds))) * 64)[:64]
             random.seed(1400 + ci)
             lrs, hrs = [], []
             for i in idx:
