@@ -71,7 +71,7 @@ static int launch_fwd_rs(const void* x, void* ya, void* yb, const void* wa, cons
   typedef BlockCfg<F, E, L> C;
   typedef __bf16 T;
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
-  static const int persist_from = getenv("SR_RS_PERSIST_FROM") ? atoi(getenv("SR_RS_PERSIST_FROM")) : 768;   // measured crossover: 3 tiles per CU
+  constexpr int persist_from = 768;                    // measured crossover: 3 tiles per CU
   const long total = (long)N * tiles_x * tiles_y;
   if (total >= persist_from && total < (1L << 31)) {   // many tiles per CU: the persistent form (one workgroup per CU)
     const int wgs = 256;
@@ -82,17 +82,15 @@ static int launch_fwd_rs(const void* x, void* ya, void* yb, const void* wa, cons
       SR_HIP_CHECK_LAUNCH();
       return 0;
     }
-    static const bool no_pipe = getenv("SR_RS_NO_PIPE") != nullptr;    // (the plain persistent loop, for A/B measurements)
     if constexpr (NBLK == 2) {
-      if (!save && !no_pipe) {                         // two blocks, nothing saved: the two-role pipeline
+      if (!save) {                                     // two blocks, nothing saved: the two-role pipeline
         hipLaunchKernelGGL((wdsr_fwd_rs_pipe_kernel<F, E, L>), dim3(wgs), dim3(512), 0, st, (const T*)x, (T*)ya, (T*)yb, (const T*)wa,
                            (const T*)wb, cia, cib, N, H, W, tiles_x, tiles_x * tiles_y);
         SR_HIP_CHECK_LAUNCH();
         return 0;
       }
-    }
-    if (!save) {
-      hipLaunchKernelGGL((wdsr_fwd_rs_persist_kernel<F, E, L, NBLK, false>), dim3(wgs), dim3(512), 0, st, (const T*)x, (T*)ya, (T*)yb,
+    } else if (!save) {
+      hipLaunchKernelGGL((wdsr_fwd_rs_persist_kernel<F, E, L, 1, false>), dim3(wgs), dim3(512), 0, st, (const T*)x, (T*)ya, (T*)yb,
                          (const T*)wa, (const T*)wb, cia, cib, (T*)tsa, (T*)tsb, N, H, W, tiles_x, tiles_x * tiles_y);
       SR_HIP_CHECK_LAUNCH();
       return 0;

@@ -38,9 +38,15 @@ __device__ unsigned long long g_sr_stamp_wgs = 0;      // workgroups the buffer 
   if (sp_ && wg_ < g_sr_stamp_wgs && (threadIdx.x & 63) == 0 && stamp_i_ < 16 && (threadIdx.x >> 6) < 16) { \
     unsigned long long* q_ = sp_ + ((wg_ * 16 + (threadIdx.x >> 6)) * 16 + stamp_i_) * 2; \
     q_[0] = __builtin_amdgcn_s_memrealtime(); q_[1] = __builtin_amdgcn_s_memtime(); } ++stamp_i_; } while (0)
+// a stamp with an explicit slot, for device functions that have no running stamp index (inner phases; diagnostic build only)
+#define SR_STAMP_AT(i_) do { unsigned long long* sp_ = g_sr_stamps; const size_t wg_ = (size_t)blockIdx.y * gridDim.x + blockIdx.x; \
+  if (sp_ && wg_ < g_sr_stamp_wgs && (threadIdx.x & 63) == 0 && (i_) < 16 && (threadIdx.x >> 6) < 16) { \
+    unsigned long long* q_ = sp_ + ((wg_ * 16 + (threadIdx.x >> 6)) * 16 + (i_)) * 2; \
+    q_[0] = __builtin_amdgcn_s_memrealtime(); q_[1] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define SR_STAMP_DECL do {} while (0)
 #define SR_STAMP() do {} while (0)
+#define SR_STAMP_AT(i_) do {} while (0)
 #endif
 
 template <typename T> struct FragOf;

@@ -35,6 +35,12 @@ struct BlockCfg {
   // packed weight blob (fragments of 512 elements)
   static constexpr int W1_OFF = 0, W2_OFF = NET * KS1, W3_OFF = W2_OFF + KS2, NFRAG_FWD = W3_OFF + KS3;
   static constexpr int CINIT_FWD = 32 + (FOLD_B1 ? 0 : NET * 32);
+  // "dense K" form of the 3x3 conv (csrc/wdsr_fwd_rs.h, packing.py W3D): the three taps of a window row are 3 L contiguous
+  // channels of the t image, cut into 4-channel chunks (15 at L = 20) + one spare = 4 k-steps per window row; the bias rides on
+  // a "ones" chunk in the last row's spare slot, the residual is the accumulator's initial value.  12 k-steps where KS3 = 15.
+  static constexpr int LC = L / 4;                                 // 4-channel chunks per tap
+  static constexpr bool DENSE3 = (L % 4 == 0) && (3 * LC + 1 == 16);
+  static constexpr int KS3D = DENSE3 ? 12 : 0;
 };
 
 // stage the halo'd x tile [NPXH_PAD][KX] into LDS: zero outside the image, ones channel at index F.

@@ -80,10 +80,15 @@ template <int F_, int E_, int L_, int NBLK_> struct RsCfg {
   // bias is ONE 16-byte constant in LDS that every lane half needing it reads (a broadcast)
   static constexpr int KXL = C::F;
   static constexpr int X0_ELEMS = npad(0) * KXL;                       // staged x
-  static constexpr int TT_ELEMS = npad(0) * C::LP;                     // t of the current block
+  static_assert(C::DENSE3, "the register-resident forward runs the 3x3 conv in its dense-K form (L % 4 == 0)");
+  static constexpr int TD = C::L;                                      // t channels per LDS row: the real ones only (40 bytes at L = 20)
+  static constexpr int TT_ELEMS = npad(0) * TD;                        // t of the current block
   static constexpr int X1_ELEMS = NBLK > 1 ? npad(1) * KXL : 0;        // block 0's output = block 1's input
-  static constexpr int ONES_ELEMS = 8;
-  static constexpr int W_ELEMS = C::NFRAG_FWD * 512;
+  static constexpr int ONES_ELEMS = 8;                                 // [1, 0, 0, 0 | 0, 0, 0, 0]: conv1's ones chunk (16 B) = the 3x3's ones chunk + zero chunk (8 B each)
+  // fragments staged per block: W1 | W2 as they lie at the head of the blob, then W3D from its tail
+  static constexpr int NFR_A = C::W2_OFF + C::KS2, NFR = NFR_A + C::KS3D, W3D_SRC = BwdCfg<C>::NFRAG;
+  static constexpr int W_ELEMS = NFR * 512;
+  static constexpr int src_frag(int fr) { return fr < NFR_A ? fr : W3D_SRC + (fr - NFR_A); }
   static constexpr int CL_FLOATS = (C::CINIT_FWD + 63) / 64 * 64;      // whole 64-float DMA pieces per block
   static constexpr int LDS_BYTES = (X0_ELEMS + TT_ELEMS + X1_ELEMS + NBLK * W_ELEMS + ONES_ELEMS) * 2 + NBLK * CL_FLOATS * 4;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -97,7 +102,7 @@ template <int F_, int E_, int L_, int NBLK_> struct RsCfg {
   static_assert(C::FC == 3, "piece geometry assumes 3 chunks per pixel");
   static_assert(NPX * PXP * C::FC * 16 + 16 <= (X0_ELEMS + TT_ELEMS) * 2, "the last x piece may spill into the (not yet written) t image only");
   static constexpr int P_C = P_X + NPX, NPC = NBLK * (CL_FLOATS / 64);
-  static constexpr int P_W = P_C + NPC, P_W1 = P_W + C::NFRAG_FWD, P_END = P_W + NBLK * C::NFRAG_FWD;
+  static constexpr int P_W = P_C + NPC, P_W1 = P_W + NFR, P_END = P_W + NBLK * NFR;
 };
 
 // register-resident weights of one phase
@@ -116,14 +121,14 @@ template <typename C> struct RwA {
   }
 };
 template <typename C> struct RwB {
-  static constexpr int N = C::KS3;
-  bf16x8 w3[C::KS3];
+  static constexpr int N = C::KS3D, OFF = C::W2_OFF + C::KS2;          // W3D sits behind W1 | W2 in the staged copy
+  bf16x8 w3[N];
   SR_DEV void load_one(const __bf16* wl, int lane, int i) {
-    if (i < N) w3[i] = lds_chunk<__bf16>(wl, ((C::W3_OFF + i) * 64 + lane) * 8);
+    if (i < N) w3[i] = lds_chunk<__bf16>(wl, ((OFF + i) * 64 + lane) * 8);
   }
   SR_DEV void load(const __bf16* wl, int lane) {
 #pragma unroll
-    for (int i = 0; i < C::KS3; ++i) w3[i] = lds_chunk<__bf16>(wl, ((C::W3_OFF + i) * 64 + lane) * 8);
+    for (int i = 0; i < N; ++i) w3[i] = lds_chunk<__bf16>(wl, ((OFF + i) * 64 + lane) * 8);
   }
 };
 
@@ -219,8 +224,12 @@ SR_DEV void rw_store_t(const f32x16& tacc, const RwPix& p, __bf16* TT, __bf16* t
       for (int j = 0; j < 4; ++j) v[g][j] = (__bf16)0.f;
     }
   }
+  // LDS rows hold the L real channels (dense-K operand of the 3x3 conv); the ones channel and the padding stay out
 #pragma unroll
-  for (int g = 0; g < C::CPT; ++g) *reinterpret_cast<bf16x4*>(TT + p.hp * C::LP + g * 8 + hh * 4) = v[g];
+  for (int g = 0; g < C::CPT; ++g) {
+    if (g * 8 + 8 <= C::L) *reinterpret_cast<bf16x4*>(TT + p.hp * C::L + g * 8 + hh * 4) = v[g];
+    else if (g * 8 + 4 <= C::L) { if (hh == 0) *reinterpret_cast<bf16x4*>(TT + p.hp * C::L + g * 8) = v[g]; }
+  }
   if constexpr (SAVE_T) {
     if (p.tso >= 0) {
 #pragma unroll
@@ -257,11 +266,13 @@ SR_DEV void rw_phase_a(const __bf16* Xin, const __bf16* ones, __bf16* TT, const 
   RwPix p = rw_pix_a<C, RW, NP, HALO>(wave * 32 + r, H, W, ty0, tx0);
   bf16x8 xb[C::KS1];
   rw_x_frags<C, KXL>(xb, Xin, ones, p.hp, hh);
+  SR_STAMP_AT(11);
   // first tile: the next phase's weights travel LDS -> registers in its MFMA gaps, PFN reads per e-tile (all at
   // once they would queue ~500 LDS cycles in front of this phase's own operands)
   constexpr int PFN = 4;
   {
     const f32x16 t = rw_t_tile<C, PFN>(xb, w, cl, hh, [&](int et) { prefetch(et * PFN, et * PFN + PFN); });
+    SR_STAMP_AT(12);
     const RwPix pc = p;
     if (wave + NW < NT) {                              // the next tile's operands land while this one is converted and stored
       p = rw_pix_a<C, RW, NP, HALO>((wave + NW) * 32 + r, H, W, ty0, tx0);
@@ -270,6 +281,7 @@ SR_DEV void rw_phase_a(const __bf16* Xin, const __bf16* ones, __bf16* TT, const 
     prefetch(C::NET * PFN, 64);                        // (whatever is left)
     before_stores();                                   // (counted-wait hook: no VMEM store of this wave has been issued yet)
     rw_store_t<C, SAVE_T>(t, pc, TT, tsave_tile, hh);
+    SR_STAMP_AT(13);
   }
 #pragma unroll 1
   for (int tile = wave + NW; tile < NT; tile += NW) {
@@ -283,58 +295,53 @@ SR_DEV void rw_phase_a(const __bf16* Xin, const __bf16* ones, __bf16* TT, const 
   }
 }
 
-// Pixel operands of the 3x3 conv.  Chunk q = 2 s + hh of k-step s is (tap, 8 channels) for q < 9 CPT and a chunk of
-// the block input (residual) after that.  A t row holds exactly CPT chunks per pixel, so the 3 CPT chunks of one
-// kernel row ky are CONSECUTIVE 16-byte pieces starting at pixel (trow + ky RWI): with the lane-half offset folded
-// into the base, every fragment is `base + constant` except the two k-steps whose halves straddle a row change.
-// Four per-lane bases, zero address arithmetic per read.
-template <typename C, int KXL, int RWI> struct RwBAddr {
-  static constexpr int ROWQ = 3 * C::CPT;                   // chunks per kernel row
-  static constexpr int NQ = 9 * C::CPT;                     // t chunks in all
-  const __bf16* bt;       // t image at (trow), + hh chunk
-  const __bf16* bx;       // x image at (xrow), + hh chunk
-  const __bf16* bsplit[2];
-  static constexpr int off_q(int q) {                        // element offset of chunk q from the UN-shifted bases; x chunks: from bx
-    return q < NQ ? (q / ROWQ) * RWI * C::LP + (q % ROWQ) * 8 : ((q - NQ) < C::FC ? (q - NQ) : 0) * 8;
-  }
-  static constexpr bool split(int s) {                       // halves not 8 elements apart in one image
-    const int q0 = 2 * s, q1 = 2 * s + 1;
-    if (q1 >= NQ + C::FC) return true;                       // padded chunk (hh = 1 reads x chunk 0)
-    if ((q0 < NQ) != (q1 < NQ)) return true;
-    return off_q(q1) - off_q(q0) != 8;
-  }
-  SR_DEV void init(const __bf16* TT, const __bf16* Xin, int hy, int hx, int hh) {
-    const __bf16* t0 = TT + (hy * RWI + hx) * C::LP;
-    const __bf16* x0 = Xin + ((hy + 1) * RWI + hx + 1) * KXL;
-    bt = t0 + hh * 8;
-    bx = x0 + hh * 8;
-    int k = 0;
-#pragma unroll
-    for (int s = 0; s < C::KS3; ++s) {
-      if (split(s)) {
-        const int q0 = 2 * s, q1 = 2 * s + 1;
-        const __bf16* a0 = (q0 < NQ ? t0 : x0) + off_q(q0);
-        const __bf16* a1 = (q1 < NQ ? t0 : x0) + off_q(q1);
-        if (k < 2) bsplit[k] = hh ? a1 : a0;
-        ++k;
-      }
-    }
-  }
-  static constexpr int nsplit() {
-    int k = 0;
-    for (int s = 0; s < C::KS3; ++s) k += split(s) ? 1 : 0;
-    return k;
+// Pixel operands of the DENSE-K 3x3 conv.  The three taps of window row ky are 3 L contiguous elements of the t image (rows of
+// L real channels: 40 bytes at L = 20, 32 consecutive pixels hit 32 different bank pairs with 8-byte reads): 15 four-channel
+// chunks, and k-step 4 ky + q gives lane half hh the chunks 8 hh + 2 q and 8 hh + 2 q + 1, i.e. 16 contiguous bytes at
+// (window row) + 64 hh + 16 q.  With the lane-half term folded into the base every read is `base + compile-time offset`:
+// one address computation per tile.  Chunk 15 of a row (half 1, q = 3) is the first chunk of the next pixel: zero weights in
+// W3D; in the last row that slot reads a "ones" chunk instead, whose weight is b3.  Against the 8-channel chunks of
+// wdsr_block.h (t rows padded to LP = 24 with the ones channel, residual as identity chunks): 12 k-steps instead of 15.
+template <typename C, int RWI> struct RwBAddrD {
+  static constexpr int TD = C::L, KS = C::KS3D;
+  static_assert(C::DENSE3 && KS == 12, "dense-K layout: 16 chunk slots per window row");
+  typedef __attribute__((address_space(3))) const volatile bf16x4* lds_chunk_p;
+  // VOLATILE 8-byte LDS reads: hipcc otherwise merges two of them -- the two of one k-step, or the first chunks of two k-steps --
+  // into one ds_read2_b64, which takes 8 LDS cycles where two ds_read_b64 take 4 (at one read pair per MFMA and four SIMDs
+  // that is the whole LDS issue rate).
+  lds_chunk_p b0;         // first chunk of this lane half in window row 0
+  lds_chunk_p last;       // second chunk of the last k-step: half 0 its chunk 7, half 1 the ones chunk
+  SR_DEV void init(const __bf16* TT, const __bf16* ones, int hy, int hx, int hh) {
+    const __bf16* g0 = TT + (hy * RWI + hx) * TD + hh * 32;
+    b0 = (lds_chunk_p)(g0);
+    last = (lds_chunk_p)(hh ? ones : g0 + 2 * RWI * TD + 3 * 8 + 4);
   }
   SR_DEV bf16x8 frag(int s) const {
-    if (split(s)) {
-      int k = 0;
-      for (int i = 0; i < s; ++i) k += split(i) ? 1 : 0;
-      return *reinterpret_cast<const bf16x8*>(bsplit[k]);
-    }
-    const int q0 = 2 * s;
-    return *reinterpret_cast<const bf16x8*>((q0 < NQ ? bt : bx) + off_q(q0));
+    const int off = ((s / 4) * RWI * TD + (s % 4) * 8) / 4;      // in 4-element chunks
+    const bf16x4 lo = b0[off];
+    const bf16x4 hi = s == KS - 1 ? *last : b0[off + 1];
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
   }
 };
+// the residual as the accumulator's initial value: rows f = 8 g + 4 hh + (0..3) of this pixel's x row (exact: bf16 -> fp32)
+template <typename C> SR_DEV f32x16 rw_resid_init(const __bf16* xrow, int hh) {
+  f32x16 acc;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g < C::FC) {
+      const bf16x4 v = *reinterpret_cast<const bf16x4*>(xrow + g * 8 + hh * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[4 * g + k] = (float)v[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[4 * g + k] = 0.f;
+    }
+  }
+  return acc;
+}
 
 struct RwPixB {
   int hy, hx;
@@ -378,22 +385,21 @@ SR_DEV void rw_store_y(const f32x16& oacc, const RwPixB& p, __bf16* Xnext, __amd
   }
 }
 
-// One 3x3 chain: (MFMA, read) pairs in source order, pinned by sched_barrier: the pixel operand of k-step s + AHEAD is
+// One 3x3 chain: (MFMA, reads) in source order, pinned by sched_barrier: the pixel operand of k-step s + AHEAD is
 // requested right after the MFMA of k-step s (a 3x3 chain is one dependent accumulation, which issues back to back at
-// full rate).  `mid()` runs LAG MFMAs into the chain: the previous tile's stores go there.
+// full rate).  `mid()` runs LAG MFMAs into the chain: the previous tile's stores go there.  `acc` = the residual.
 template <typename C, typename A, int AHEAD, int LAG, typename MID, typename PF>
-SR_DEV f32x16 rw_b_chain(const A& a, const RwB<C>& w, MID mid, PF pf) {
-  constexpr int KS3 = C::KS3;
-  bf16x8 f[KS3];
+SR_DEV f32x16 rw_b_chain(const A& a, const RwB<C>& w, f32x16 acc, MID mid, PF pf) {
+  constexpr int KS = C::KS3D;
+  bf16x8 f[KS];
 #pragma unroll
   for (int s = 0; s < AHEAD; ++s) f[s] = a.frag(s);
-  f32x16 acc = zero16();
   SR_RS_PRIO(SR_RS_PRIO_B);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int s = 0; s < KS3; ++s) {
+  for (int s = 0; s < KS; ++s) {
     acc = mma16<__bf16>(w.w3[s], f[s], acc);
-    if (s + AHEAD < KS3) f[s + AHEAD] = a.frag(s + AHEAD);
+    if (s + AHEAD < KS) f[s + AHEAD] = a.frag(s + AHEAD);
     pf(s);
     __builtin_amdgcn_sched_barrier(0);
     if (s == LAG) {
@@ -406,33 +412,39 @@ SR_DEV f32x16 rw_b_chain(const A& a, const RwB<C>& w, MID mid, PF pf) {
 }
 
 template <typename C, int KXL, int RWO, int NPO, int HALOO, int NW, typename PF>
-SR_DEV void rw_phase_b(const __bf16* TT, const __bf16* Xin, __bf16* Xnext, __bf16* yout, const RwB<C>& w, int H, int W, int ty0,
-                       int tx0, int wave, int lane, PF prefetch) {
+SR_DEV void rw_phase_b(const __bf16* TT, const __bf16* Xin, const __bf16* ones, __bf16* Xnext, __bf16* yout, const RwB<C>& w, int H,
+                       int W, int ty0, int tx0, int wave, int lane, PF prefetch) {
   constexpr int NT = (NPO + 31) / 32, RWI = RWO + 2, AHEAD = 4, LAG = 4;
-  typedef RwBAddr<C, KXL, RWI> A;
-  static_assert(A::nsplit() <= 2, "two straddling k-steps at most");
+  typedef RwBAddrD<C, RWI> A;
   const int r = lane & 31, hh = lane >> 5;
   if (wave >= NT) {                                    // wave-uniform
     prefetch(0, 64);
     return;
   }
+  SR_STAMP_AT(6);
   const bool to_global = yout != nullptr;
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yout, 0, to_global ? H * W * C::F * 2 : 0, 0x00020000);
   RwPixB p = rw_pix_b<C, KXL, RWO, NPO, HALOO>(wave, r, H, W, ty0, tx0);
   A a;
-  a.init(TT, Xin, p.hy, p.hx, hh);
+  a.init(TT, ones, p.hy, p.hx, hh);
+  SR_STAMP_AT(7);
   // first tile: nothing to store yet; the next phase's weights travel LDS -> registers two reads per MFMA
-  f32x16 acc = rw_b_chain<C, A, AHEAD, LAG>(a, w, [] {}, [&](int s) { prefetch(2 * s, 2 * s + 2); });
-  prefetch(2 * C::KS3, 64);
+  f32x16 acc = rw_b_chain<C, A, AHEAD, LAG>(a, w, rw_resid_init<C>(Xin + ((p.hy + 1) * RWI + p.hx + 1) * KXL, hh), [] {},
+                                            [&](int s) { prefetch(2 * s, 2 * s + 2); });
+  prefetch(2 * C::KS3D, 128);
+  SR_STAMP_AT(8);
 #pragma unroll 1
   for (int tile = wave + NW; tile < NT; tile += NW) {
     const RwPixB pp = p;
     const f32x16 pacc = acc;
     p = rw_pix_b<C, KXL, RWO, NPO, HALOO>(tile, r, H, W, ty0, tx0);
-    a.init(TT, Xin, p.hy, p.hx, hh);
-    acc = rw_b_chain<C, A, AHEAD, LAG>(a, w, [&] { rw_store_y<C>(pacc, pp, Xnext, yrs, to_global, hh); }, [](int) {});
+    a.init(TT, ones, p.hy, p.hx, hh);
+    acc = rw_b_chain<C, A, AHEAD, LAG>(a, w, rw_resid_init<C>(Xin + ((p.hy + 1) * RWI + p.hx + 1) * KXL, hh),
+                                       [&] { rw_store_y<C>(pacc, pp, Xnext, yrs, to_global, hh); }, [](int) {});
   }
+  SR_STAMP_AT(9);
   rw_store_y<C>(acc, p, Xnext, yrs, to_global, hh);
+  SR_STAMP_AT(10);
 }
 
 // grid = (tiles_y * tiles_x, N), 512 threads.  NBLK = 1: x -> yb (ya, wb, cib, tsb unused).  NBLK = 2: x -> ya (block
@@ -487,7 +499,7 @@ __global__ __launch_bounds__(512) void wdsr_fwd_rs_kernel(const __bf16* __restri
         dma_piece4(src, lds_addr(CL) + k * 256);
       } else {                                         // weight fragments as they lie
         const int fr = p - R::P_W;
-        const __bf16* wsrc = (NBLK > 1 && fr >= C::NFRAG_FWD) ? wb + (size_t)(fr - C::NFRAG_FWD) * 512 : wa + (size_t)fr * 512;
+        const __bf16* wsrc = (NBLK > 1 && fr >= R::NFR) ? wb + (size_t)R::src_frag(fr - R::NFR) * 512 : wa + (size_t)R::src_frag(fr) * 512;
         dma_piece16(reinterpret_cast<const char*>(wsrc + lane * 8), lds_addr(WL) + fr * 1024);
       }
     }
@@ -523,9 +535,9 @@ __global__ __launch_bounds__(512) void wdsr_fwd_rs_kernel(const __bf16* __restri
   __syncthreads();
   SR_STAMP();
   if constexpr (NBLK == 1) {
-    rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NW>(TT, X0, nullptr, yb + img, rwb, H, W, ty0, tx0, wave, lane, [](int, int) {});
+    rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NW>(TT, X0, ONES, nullptr, yb + img, rwb, H, W, ty0, tx0, wave, lane, [](int, int) {});
   } else {
-    rw_phase_b<C, KXL, R::rw(1), R::np(1), NBLK - 1, NW>(TT, X0, X1, ya ? ya + img : nullptr, rwb, H, W, ty0, tx0, wave, lane,
+    rw_phase_b<C, KXL, R::rw(1), R::np(1), NBLK - 1, NW>(TT, X0, ONES, X1, ya ? ya + img : nullptr, rwb, H, W, ty0, tx0, wave, lane,
                                                          [&](int lo, int hi) { pf_a(WL + R::W_ELEMS, lo, hi); });
     SR_STAMP();
     __syncthreads();
@@ -536,7 +548,7 @@ __global__ __launch_bounds__(512) void wdsr_fwd_rs_kernel(const __bf16* __restri
     SR_STAMP();
     __syncthreads();
     SR_STAMP();
-    rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NW>(TT, X1, nullptr, yb + img, rwb, H, W, ty0, tx0, wave, lane, [](int, int) {});
+    rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NW>(TT, X1, ONES, nullptr, yb + img, rwb, H, W, ty0, tx0, wave, lane, [](int, int) {});
   }
   SR_STAMP();
 }
@@ -605,7 +617,7 @@ __global__ __launch_bounds__(512) void wdsr_fwd_rs_persist_kernel(const __bf16* 
         dma_piece4(src, lds_addr(CL) + k * 256);
       } else {
         const int fr = p - R::P_W;
-        const __bf16* wsrc = (NBLK > 1 && fr >= C::NFRAG_FWD) ? wb + (size_t)(fr - C::NFRAG_FWD) * 512 : wa + (size_t)fr * 512;
+        const __bf16* wsrc = (NBLK > 1 && fr >= R::NFR) ? wb + (size_t)R::src_frag(fr - R::NFR) * 512 : wa + (size_t)R::src_frag(fr) * 512;
         dma_piece16(reinterpret_cast<const char*>(wsrc + lane * 8), lds_addr(WL) + fr * 1024);
       }
     }
@@ -648,17 +660,17 @@ __global__ __launch_bounds__(512) void wdsr_fwd_rs_persist_kernel(const __bf16* 
                                                                [&](int lo, int hi) { pf_b(WL, lo, hi); }, [] {});
     __syncthreads();
     if constexpr (NBLK == 1) {
-      rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NW>(TT, X0, nullptr, yb + img, rwb, H, W, ty0, tx0, wave, lane,
+      rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NW>(TT, X0, ONES, nullptr, yb + img, rwb, H, W, ty0, tx0, wave, lane,
                                                       [&](int lo, int hi) { if (more) pf_a(WL, lo, hi); });
     } else {
-      rw_phase_b<C, KXL, R::rw(1), R::np(1), NBLK - 1, NW>(TT, X0, X1, ya ? ya + img : nullptr, rwb, H, W, ty0, tx0, wave, lane,
+      rw_phase_b<C, KXL, R::rw(1), R::np(1), NBLK - 1, NW>(TT, X0, ONES, X1, ya ? ya + img : nullptr, rwb, H, W, ty0, tx0, wave, lane,
                                                            [&](int lo, int hi) { pf_a(WL + R::W_ELEMS, lo, hi); });
       __syncthreads();
       // ---- block 1 ----
       rw_phase_a<C, KXL, R::rw(1), R::np(1), NBLK - 1, NW, SAVE_T>(X1, ONES, TT, rwa, CL + R::CL_FLOATS, tsb_tile, H, W, ty0, tx0, wave,
                                                                    lane, [&](int lo, int hi) { pf_b(WL + R::W_ELEMS, lo, hi); }, [] {});
       __syncthreads();
-      rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NW>(TT, X1, nullptr, yb + img, rwb, H, W, ty0, tx0, wave, lane,
+      rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NW>(TT, X1, ONES, nullptr, yb + img, rwb, H, W, ty0, tx0, wave, lane,
                                                       [&](int lo, int hi) { if (more) pf_a(WL, lo, hi); });
     }
     cur ^= 1;
@@ -688,7 +700,7 @@ __global__ __launch_bounds__(512) void wdsr_fwd_rs_pipe_kernel(const __bf16* __r
   typedef RsCfg<F, E, L, 2> R;
   constexpr int NR = 4;                                                // waves per role
   constexpr int X0S = R::X0_ELEMS + 512;                               // x region + its DMA slack
-  constexpr int TT0_ELEMS = R::npad(0) * C::LP, TT1_ELEMS = R::npad(1) * C::LP, X1_ELEMS = R::npad(1) * R::KXL;
+  constexpr int TT0_ELEMS = R::npad(0) * R::TD, TT1_ELEMS = R::npad(1) * R::TD, X1_ELEMS = R::npad(1) * R::KXL;
   constexpr int BUF_ELEMS = 2 * X0S + TT0_ELEMS + 2 * X1_ELEMS + TT1_ELEMS;
   constexpr int LDS_BYTES = (BUF_ELEMS + R::ONES_ELEMS) * 2 + 2 * R::CL_FLOATS * 4;
   static_assert((TT0_ELEMS + 2 * X1_ELEMS + TT1_ELEMS) >= 2 * R::W_ELEMS, "the weights are parked behind the x buffers until they are in registers");
@@ -744,7 +756,7 @@ __global__ __launch_bounds__(512) void wdsr_fwd_rs_pipe_kernel(const __bf16* __r
       dma_piece4(src, lds_addr(CL) + k * 256);
     } else {
       const int fr = p - R::P_W;
-      const __bf16* wsrc = fr >= C::NFRAG_FWD ? wb + (size_t)(fr - C::NFRAG_FWD) * 512 : wa + (size_t)fr * 512;
+      const __bf16* wsrc = fr >= R::NFR ? wb + (size_t)R::src_frag(fr - R::NFR) * 512 : wa + (size_t)R::src_frag(fr) * 512;
       dma_piece16(reinterpret_cast<const char*>(wsrc + lane * 8), lds_addr(WL) + fr * 1024);
     }
   }
@@ -791,7 +803,7 @@ __global__ __launch_bounds__(512) void wdsr_fwd_rs_pipe_kernel(const __bf16* __r
         int ty0, tx0;
         size_t img;
         tile_of(j - 2, ty0, tx0, img);
-        rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NR>(TT1, X1 + ((j - 2) & 1) * X1_ELEMS, nullptr, yb + img, w1, H, W, ty0, tx0, bw, lane,
+        rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NR>(TT1, X1 + ((j - 2) & 1) * X1_ELEMS, ONES, nullptr, yb + img, w1, H, W, ty0, tx0, bw, lane,
                                                         [](int, int) {});
       }
       __syncthreads();
@@ -799,7 +811,7 @@ __global__ __launch_bounds__(512) void wdsr_fwd_rs_pipe_kernel(const __bf16* __r
         int ty0, tx0;
         size_t img;
         tile_of(j, ty0, tx0, img);
-        rw_phase_b<C, KXL, R::rw(1), R::np(1), 1, NR>(TT0, X0 + (j & 1) * X0S, X1 + (j & 1) * X1_ELEMS, ya ? ya + img : nullptr, w0, H, W,
+        rw_phase_b<C, KXL, R::rw(1), R::np(1), 1, NR>(TT0, X0 + (j & 1) * X0S, ONES, X1 + (j & 1) * X1_ELEMS, ya ? ya + img : nullptr, w0, H, W,
                                                       ty0, tx0, bw, lane, [](int, int) {});
       }
       wait_vmcnt<0>();

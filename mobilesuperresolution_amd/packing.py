@@ -178,7 +178,7 @@ def block_tables(F: int, E: int, L: int):
     """Tables for all residual-block kernels (forward, backward-data, weight-gradient).
 
     Blob sections (in 512-element fragments), forward first so wdsr_block_fwd_kernel's offsets hold:
-      W1 | W2 | W3 | W3T | W2T | W1T | ID | W2N
+      W1 | W2 | W3 | W3T | W2T | W1T | ID | W2N | W3D (L = 20 only)
     C-init floats: b2c[32] | b1c[NET][32] (only when b1 is not folded) | b1n[NET*32] (same condition).
     """
     fwd = block_fwd_tables(F, E, L)
@@ -221,18 +221,40 @@ def block_tables(F: int, E: int, L: int):
     l = k_natural(ks, hh, j)
     w2n = _sel((e < E) & (l < L), o["w2"] + np.minimum(l, L - 1) * E + np.minimum(e, E - 1), Z)
 
-    w = np.concatenate([fwd["w"]] + [a.reshape(-1) for a in (w3t, w2t, w1t, ident, w2n)])
+    # W3D ("dense K", round 3): the 3x3 conv as ONE contraction over (window row ky, row chunk rc): the three taps of a window
+    # row are 3 L contiguous elements of the t image (L real channels per pixel), cut into 4-channel chunks rc = 0 .. 3 L / 4 - 1;
+    # k-step s = 4 ky + q gives lane half hh the chunks rc = 8 hh + 2 q + (j >> 2), i.e. 16 contiguous bytes at (window row
+    # base) + 64 hh + 16 q: the same compile-time offset for both halves.  At L = 20 a row has 15 chunks: rc = 15 (the next
+    # pixel's first chunk) gets zero weights, except in the last row where the kernel reads a "ones" chunk there whose first
+    # slot carries b3.  12 k-steps where the 8-channel chunks of W3 (LP = 24 with the ones channel, plus the identity chunks
+    # of the residual) need 15: the residual is the accumulator's initial value instead (csrc/wdsr_fwd_rs.h, rw_phase_b).
+    w3d = None
+    if 3 * (L // 4) + 1 == 16 and L % 4 == 0:
+        LC = L // 4
+        KS3D = 12
+        s, r, hh, j = _grid(KS3D)
+        ky, q = s // 4, s % 4
+        rc = 8 * hh + 2 * q + (j >> 2)
+        jj = j & 3
+        tap, l = 3 * ky + np.minimum(rc, 3 * LC - 1) // LC, 4 * (rc % LC) + jj
+        rf = np.minimum(r, F - 1)
+        w3d = _sel((rc < 3 * LC) & (r < F), o["w3"] + (rf * L + np.minimum(l, L - 1)) * 9 + np.minimum(tap, 8), Z)
+        w3d = _sel((rc == 3 * LC) & (ky == 2) & (jj == 0) & (r < F), o["b3"] + rf, w3d)
+    else:
+        KS3D = 0
+
+    w = np.concatenate([fwd["w"]] + [a.reshape(-1) for a in (w3t, w2t, w1t, ident, w2n)] + ([w3d.reshape(-1)] if w3d is not None else []))
     cin = [fwd["cinit"]]
     if not g.fold_b1:
         ee = np.arange(g.NET * 32)
         cin.append(np.where(ee < E, o["b1"] + np.minimum(ee, E - 1), Z))
     sec, off = {}, 0
     for name, n in (("W1", g.NET * g.KS1), ("W2", g.KS2), ("W3", g.KS3), ("W3T", KS3B), ("W2T", g.NET * 2),
-                    ("W1T", g.KS2), ("ID", KSI), ("W2N", g.NET * 2)):
+                    ("W1T", g.KS2), ("ID", KSI), ("W2N", g.NET * 2), ("W3D", KS3D)):
         sec[name] = off
         off += n
     assert off * 512 == w.size
-    return dict(w=w, cinit=np.concatenate(cin), sec=sec, nfrag=off, geom=g, KS3B=KS3B, KSI=KSI)
+    return dict(w=w, cinit=np.concatenate(cin), sec=sec, nfrag=off, geom=g, KS3B=KS3B, KSI=KSI, KS3D=KS3D)
 
 
 # ---- accumulator-layout slabs written by the weight-gradient kernels -> canonical gradients ----

@@ -300,3 +300,48 @@ def emu_block_wgrad3(x_nhwc, dy_nhwc, packed_w, cinit_tab, tab, dtype="f32", TH=
                         dW3T[u] = mma16(tT[s], _tr_frag(DY, hof, s, R), dW3T[u])
     out = np.concatenate([a.T.reshape(-1) for a in dW3T])          # [tile][reg][lane]
     return out if slab is None else slab + out
+
+
+def emu_conv3_dense(t_nhwc, x_nhwc, packed_w3d, L, F, dtype="f32"):
+    """Mirror of rw_phase_b / RwBAddrD / rw_resid_init (csrc/wdsr_fwd_rs.h): the dense-K 3x3 conv + bias + residual of one image.
+    t_nhwc (H, W, L), x_nhwc (H, W, F).  The t image is laid out as the kernel's LDS region: row-major over a (H + 2) x (W + 2)
+    region (zeros outside the image), rows of L real channels; output tiles are 32 consecutive pixels of the H x W core region
+    numbered row-major over a region of width RWO = W (region pixel (hy, hx) <-> window top-left t row (hy, hx))."""
+    H, W, _ = t_nhwc.shape
+    RWO, RWI, TD = W, W + 2, L
+    NPI = (H + 2) * RWI
+    T = np.zeros(((NPI + 31) // 32 * 32 + 32) * TD)                  # + slack rows, as the LDS image has behind it
+    Tv = T[:NPI * TD].reshape(H + 2, RWI, TD)
+    Tv[1:H + 1, 1:W + 1] = rnd(t_nhwc, dtype)
+    ones = np.zeros(8)
+    ones[0] = 1.0
+    X = rnd(x_nhwc, dtype)
+    pw = rnd(packed_w3d, dtype)
+    y = np.zeros((H, W, F))
+    NPO = H * RWO
+    for tile in range((NPO + 31) // 32):
+        hp = tile * 32 + R
+        hpc = np.where(hp < NPO, hp, 0)
+        hy, hx = hpc // RWO, hpc % RWO
+        acc = np.zeros((64, 16))
+        for g in range(4):                                          # rw_resid_init: rows f = 8 g + 4 hh + k of this pixel's x row
+            for k in range(4):
+                f = 8 * g + 4 * HH + k
+                acc[:, 4 * g + k] = np.where(f < F, X[hy, hx, np.minimum(f, F - 1)], 0.0) if g < F // 8 else 0.0
+        b0 = (hy * RWI + hx) * TD + HH * 32
+        for s in range(12):
+            off = (s // 4) * RWI * TD + (s % 4) * 8
+            b = np.zeros((64, 8))
+            for l in range(64):
+                b[l, :4] = T[b0[l] + off:b0[l] + off + 4]
+                if s == 11 and HH[l]:
+                    b[l, 4:] = ones[:4]
+                else:
+                    b[l, 4:] = T[b0[l] + off + 4:b0[l] + off + 8]
+            acc = mma16(wfrag(pw, s), b, acc)
+        for l in range(64):
+            if hp[l] < NPO:
+                for g in range(F // 8):
+                    for k in range(4):
+                        y[hy[l], hx[l], 8 * g + 4 * HH[l] + k] = acc[l, 4 * g + k]
+    return y

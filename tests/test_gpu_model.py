@@ -316,8 +316,8 @@ def test_static_weights_two_segment_mode_repacks_after_optimizer_step():
     master buffer's: the packed-weights key must follow the segments, or an eval forward after a step would run on the
     pre-step weights.  Checked against the one-parameter model carrying the same (stepped) weights."""
     torch.manual_seed(10)
-    m2 = _model(_ns(num_blocks=2, hot_dtype="bf16", hot_grad_segments=2))
-    m1 = _model(_ns(num_blocks=2, hot_dtype="bf16"))
+    m2 = _model(_ns(num_blocks=4, hot_dtype="bf16", hot_grad_segments=2))
+    m1 = _model(_ns(num_blocks=4, hot_dtype="bf16"))
     x = torch.rand(2, 3, 20, 28, device="cuda")
     hr = torch.rand(2, 3, 80, 112, device="cuda")
     m2.assume_static_weights = True

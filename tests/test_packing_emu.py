@@ -101,3 +101,33 @@ def test_block_bwd_tables_match_golden(golden_dir, f):
         exp = d["g/" + k]
         err = (p.grad - exp).abs().max().item()
         assert err <= 1e-4 * exp.abs().max().item(), (k, err)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 3e-6), ("bf16", 6e-3)])
+def test_dense_k_conv3_tables_match_golden(golden_dir, dtype, tol):
+    """W3D (packing.block_tables) + the dense-K addressing of csrc/wdsr_fwd_rs.h (RwBAddrD: 16 contiguous bytes per lane half
+    and k-step, the ones chunk in the last slot, the residual as accumulator init) against the reference block's own t -> y
+    (G2: y = conv3x3(t) + b3 + x)"""
+    d = _load(golden_dir, "g2_block_f24.npz")
+    tab = P.block_tables(24, 144, 20)
+    g = tab["geom"]
+    src = block_src(d, g)
+    sec = tab["sec"]
+    assert tab["KS3D"] == 12 and tab["nfrag"] == sec["W3D"] + 12
+    w3d = src[tab["w"]][sec["W3D"] * 512:(sec["W3D"] + 12) * 512]
+    t = d["t2"][0].permute(1, 2, 0).double().numpy() if "t2" in d else None
+    x = d["x"][0].permute(1, 2, 0).double().numpy()
+    if t is None:                                                    # the fixture names its intermediates differently: recompute t
+        import torch.nn.functional as Fn
+        sd = {k[2:]: v for k, v in d.items() if k.startswith("p/")}
+        w1 = O.weight_norm(sd["body.0.weight_v"], sd["body.0.weight_g"])
+        w2 = O.weight_norm(sd["body.2.weight_v"], sd["body.2.weight_g"])
+        tt = Fn.conv2d(Fn.relu(Fn.conv2d(d["x"][:1], w1, sd["body.0.bias"])), w2, sd["body.2.bias"])
+        t = tt[0].permute(1, 2, 0).double().numpy()
+    y = M.emu_conv3_dense(t, x, w3d, 20, 24, dtype=dtype)
+    import torch.nn.functional as Fn
+    sd = {k[2:]: v for k, v in d.items() if k.startswith("p/")}
+    w3 = O.weight_norm(sd["body.3.weight_v"], sd["body.3.weight_g"]).double()
+    exp = Fn.conv2d(torch.from_numpy(t).permute(2, 0, 1)[None], w3, sd["body.3.bias"].double(), padding=1)[0].permute(1, 2, 0).numpy() + x
+    err = np.abs(y - exp).max() / np.abs(exp).max()
+    assert err <= tol, err
