@@ -4,6 +4,7 @@
 #include "../../include/sr_hotpath.h"
 #include "wdsr_block.h"
 #include "wdsr_fwd_rs.h"
+#include "wdsr_fwd_stream.h"
 #include "wdsr_wgrad_rs.h"
 #include "wdsr_ends.h"
 #include "wdsr_prep.h"
@@ -64,6 +65,13 @@ int launch_block_wgrad(const void* x, const void* dy, const void* wblob, const f
 
 }  // namespace
 
+// one image per workgroup pays from one image per CU on, when the last round of workgroups is at least ~70 % full
+static bool fwd_stream_applies(long N, int H, int W) {
+  if (W != 48 || H % 4 != 0 || H < 8 || H > 4096 || N < 256) return false;
+  const long rounds = (N + 255) / 256;
+  return N * 10 >= rounds * 256 * 7;
+}
+
 // forward with register-resident weights (csrc/wdsr_fwd_rs.h): nblk = 1 (x -> yb) or 2 (x -> ya -> yb)
 template <int F, int E, int L, int NBLK>
 static int launch_fwd_rs(const void* x, void* ya, void* yb, const void* wa, const void* wb, const float* cia, const float* cib,
@@ -73,6 +81,20 @@ static int launch_fwd_rs(const void* x, void* ya, void* yb, const void* wa, cons
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
   constexpr int persist_from = 768;                    // measured crossover: 3 tiles per CU
   const long total = (long)N * tiles_x * tiles_y;
+  if constexpr (NBLK == 2) {
+    // whole 48-wide images, at least one per CU and the last round of workgroups reasonably full: the streaming kernel
+    // (csrc/wdsr_fwd_stream.h: no halo recompute, one barrier per band), with or without the saved t images
+    if (fwd_stream_applies(N, H, W)) {
+      if (tsa && tsb)
+        hipLaunchKernelGGL((wdsr_fwd_stream_kernel<F, E, L, true>), dim3(N), dim3(512), 0, st, (const T*)x, (T*)ya, (T*)yb, (const T*)wa,
+                           (const T*)wb, cia, cib, (T*)tsa, (T*)tsb, H);
+      else
+        hipLaunchKernelGGL((wdsr_fwd_stream_kernel<F, E, L, false>), dim3(N), dim3(512), 0, st, (const T*)x, (T*)ya, (T*)yb, (const T*)wa,
+                           (const T*)wb, cia, cib, (T*)nullptr, (T*)nullptr, H);
+      SR_HIP_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   if (total >= persist_from && total < (1L << 31)) {   // many tiles per CU: the persistent form (one workgroup per CU)
     const int wgs = 256;
     const bool save = tsa && (NBLK == 1 || tsb);
@@ -773,7 +795,8 @@ extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int flags, sr_stream_
   char* cur = acts;
   // inference over many tiles per CU: the persistent two-block launches (csrc/wdsr_fwd_rs.h) beat the single-block ones
   // again (0.29 vs 0.27 of the roof at batch 512); with saved images (training) the large grids stay on single blocks
-  const bool pairs = net_uses_pairs(n) || (!save_acts && n->F == 24 && n->dtype == SR_DTYPE_BF16 && net_tiles(n) >= 768);
+  const bool pairs = net_uses_pairs(n) || (n->F == 24 && n->dtype == SR_DTYPE_BF16 &&
+                                           ((!save_acts && net_tiles(n) >= 768) || fwd_stream_applies(n->N, n->H, n->W)));
   const bool saved = net_saves_side_images(n, false);
   const size_t side = side_image_bytes(n);
   for (int i = 0; i < n->NB; ++i) {

@@ -382,3 +382,45 @@ def test_persistent_forward_for_many_tiles_bit_identical(shape):
     assert torch.equal(q1[:m], q_small)
     _assert_same_up_to_summation_order(q1, y1, "one block")
     assert torch.equal(torch.nan_to_num(ts[:m], nan=-7.0), torch.nan_to_num(ts_small, nan=-7.0))
+
+
+@pytest.mark.parametrize("shape", [(256, 48, 48), (384, 20, 48), (512, 8, 48)])
+def test_streaming_forward_for_whole_images_bit_identical(shape):
+    """>= 256 images of width 48 (H % 4 == 0): sr_wdsr_fwd_rs with two blocks takes the streaming kernel (csrc/wdsr_fwd_stream.h:
+    one image per workgroup, bands of four rows, row rings in LDS, no halo recompute).  Same per-pixel arithmetic as the tile
+    kernels: block outputs and both saved t images equal the per-tile launches of sub-batches bit for bit, with and without
+    the saved images, with and without block 0's output"""
+    from mobilesuperresolution_amd import _lib as L, hotpath as HP
+    n, h, w = shape
+    f = 24
+    g = torch.Generator().manual_seed(41)
+    src = (torch.randn(2, HP.tables(f, torch.device("cuda", 0))["src_size"], generator=g) * 0.08).cuda()
+    src[:, -2], src[:, -1] = 0.0, 1.0
+    blob, cinit = HP.pack_blocks(src, f, torch.bfloat16)
+    x = torch.randn(n, h, w, f, generator=g).cuda().bfloat16()
+    tiles = ((h + 11) // 12) * ((w + 23) // 24)
+    lib = L.lib()
+
+    def run(xs, save, want_a):
+        m = xs.shape[0]
+        a = torch.full_like(xs, float("nan")) if want_a else None
+        b = torch.full_like(xs, float("nan"))
+        ts = torch.full((2, m, tiles, 288, 24), float("nan"), device="cuda", dtype=torch.bfloat16) if save else None
+        L.check(lib.sr_wdsr_fwd_rs(xs.data_ptr(), a.data_ptr() if want_a else None, b.data_ptr(), blob[0].data_ptr(), blob[1].data_ptr(),
+                                   cinit[0].data_ptr(), cinit[1].data_ptr(), ts[0].data_ptr() if save else None,
+                                   ts[1].data_ptr() if save else None, 2, m, h, w, f, 1, L.stream_ptr()), "rs2")
+        torch.cuda.synchronize()
+        return a, b, ts
+
+    m = 7                                                 # sub-batch: per-tile launches
+    ra, rb, rts = run(x[:m].contiguous(), True, True)
+    ra2, rb2, rts2 = run(x[n - m:].contiguous(), True, True)
+    for save, want_a in ((True, True), (False, True), (False, False)):
+        a, b, ts = run(x, save, want_a)
+        assert torch.isfinite(b.float()).all()
+        assert torch.equal(b[:m], rb) and torch.equal(b[n - m:], rb2)
+        if want_a:
+            assert torch.equal(a[:m], ra) and torch.equal(a[n - m:], ra2)
+        if save:
+            nn = lambda t: torch.nan_to_num(t.float(), nan=-7.0)
+            assert torch.equal(nn(ts[:, :m]), nn(rts)) and torch.equal(nn(ts[:, n - m:]), nn(rts2))
