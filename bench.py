@@ -262,10 +262,17 @@ def main():
         blob, cin = st.blob_body, st.cinit_body
         pair = args.dtype == "bf16" and UNITS == 24          # the two-block kernel is what the step launches
 
-        def rs_chain(nblk, src, d1, d2, batch):
+        def rs_chain(nblk, src, d1, d2, batch, ts=None):
             L.launch("sr_wdsr_fwd_rs_repeat", L.lib().sr_wdsr_fwd_rs_repeat, src.data_ptr(), d1.data_ptr(), d2.data_ptr(),
                      blob[BLOCKS - 2].data_ptr(), blob[BLOCKS - 1].data_ptr(), cin[BLOCKS - 2].data_ptr(),
-                     cin[BLOCKS - 1].data_ptr(), nblk, batch, LR, LR, UNITS, L.DTYPE_CODE[tdt], reps, L.stream_ptr())
+                     cin[BLOCKS - 1].data_ptr(), ts[0].data_ptr() if ts is not None else None,
+                     ts[1].data_ptr() if ts is not None and nblk == 2 else None, nblk, batch, LR, LR, UNITS, L.DTYPE_CODE[tdt], reps,
+                     L.stream_ptr())
+
+        # the variant the TIMED training step launches also keeps the two t images for the weight-gradient kernels (SAVE_T):
+        # that one is quoted as `frac`; the inference variant (nothing saved) beside it
+        tiles = (LR // 12) * (LR // 24)
+        ts32 = torch.empty((2, BATCH, tiles, 288, 24), device=dev, dtype=torch.bfloat16) if pair else None
 
         def chain1():
             if pair:
@@ -275,6 +282,9 @@ def main():
                      L.DTYPE_CODE[tdt], reps, L.stream_ptr())
 
         def chain2():
+            rs_chain(2, a, b, c, BATCH, ts32)
+
+        def chain2_inf():
             rs_chain(2, a, b, c, BATCH)
 
         def timed(chain, repeats=5):
@@ -292,15 +302,17 @@ def main():
             return sorted(ts)[len(ts) // 2]
         us1 = timed(chain1)
         us = timed(chain2) if pair else us1
+        us_inf = timed(chain2_inf) if pair else None
         units = 2 if pair else 1                              # residual blocks per launch
         alg_launch = units * alg["sr_wdsr_block_fwd"]
         achieved = alg_launch / (us * 1e-6) / 1e9
         calls = {k: round(v[1] * 1e3, 1) for k, v in timer.summary().items()}
         traffic = None                                   # PMC bytes per launch, collected offline with rocprofv3 --pmc
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_fwd_rs2.json" if pair else "r01_pmc_block_fwd.json")
+        pmc = os.path.join(ROOT, "profiles", ("r03_pmc_fwd_rs2.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_fwd_rs2.json"))
+                                              else "r02_pmc_fwd_rs2.json") if pair else "r01_pmc_block_fwd.json")
         if args.dtype == "bf16" and os.path.exists(pmc):
             traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
-        kname = "wdsr_fwd_rs_kernel<24,144,20,2,false>" if pair else f"wdsr_block_fwd_kernel<{args.dtype},24,144,20>"
+        kname = "wdsr_fwd_rs_kernel<24,144,20,2,true>" if pair else f"wdsr_block_fwd_kernel<{args.dtype},24,144,20>"
         roofline = {"kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "alg_bytes_per_launch": alg_launch, "blocks_per_launch": units, "avg_launch_us": round(us, 2),
@@ -308,14 +320,19 @@ def main():
                                             "achieved": round(alg["sr_wdsr_block_fwd"] / (us1 * 1e-6) / 1e9, 1)},
                     "how": f"median of 5 chains of {reps} back-to-back launches from one C call each, HIP events on the launch stream "
                            "(includes inter-launch gaps); algorithmic bytes = SURVEY 8(d) per-block figure "
-                           "(read x + write y) x blocks per launch"}
+                           "(read x + write y) x blocks per launch; the kernel is the SAVE_T variant the timed training step launches "
+                           "(it also writes the two t images, 7 MB, which the algorithmic figure does not count); the three 3.5 MB "
+                           "activation buffers the chain ping-pongs stay in L2 / Infinity Cache"}
+        if pair:
+            roofline["inference_variant"] = {"kernel": "wdsr_fwd_rs_kernel<24,144,20,2,false>", "avg_launch_us": round(us_inf, 2),
+                                             "frac": round(alg_launch / (us_inf * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
         if pair:
             # What bounds the kernel AS BUILT is the matrix pipe, not HBM: per 12x24 tile a workgroup issues 19 MFMAs
-            # (conv1: 5 e-tiles x 2 k-steps, conv2: 9 k-steps) per 32-pixel tile of t and 15 per 32-pixel tile of the
-            # 3x3, over the halo'd regions 28x16 -> 26x14 -> 24x12 (14 / 12 / 12 / 9 pixel tiles): padding (24->32,
+            # (conv1: 5 e-tiles x 2 k-steps, conv2: 9 k-steps) per 32-pixel tile of t and 12 per 32-pixel tile of the
+            # dense-K 3x3, over the halo'd regions 28x16 -> 26x14 -> 24x12 (14 / 12 / 12 / 9 pixel tiles): padding (24->32,
             # 144->160, 20->32 channels) and halo recompute included.  32x32x16 bf16 = 32 768 flop, 32 cycles on one of
             # the CU's four matrix pipes at 2.4 GHz.  `frac` stays the HBM figure the target (0.60) is stated in.
-            mfma_per_wg = 19 * (14 + 12) + 15 * (12 + 9)        # = SQ_INSTS_MFMA / 256 of profiles/r02_pmc_sq_fwd_rs2.json
+            mfma_per_wg = 19 * (14 + 12) + 12 * (12 + 9)        # dense-K 3x3: 12 k-steps (15 before round 3)
             wgs = BATCH * (LR // 12) * (LR // 24)
             rounds = -(-wgs // 256)                           # one 133 KB-LDS workgroup per CU at a time
             floor_us = rounds * mfma_per_wg / 4 * 32 / 2.4e3
@@ -331,11 +348,19 @@ def main():
             for _ in range(2):                                # 32 launches of ~0.1 ms per chain: let the clocks settle on this grid
                 rs_chain(2, a5, b5, c5, big)
             us5 = timed(lambda: rs_chain(2, a5, b5, c5, big))
+            ts5 = torch.empty((2, big, tiles, 288, 24), device=dev, dtype=torch.bfloat16)
+            us5s = timed(lambda: rs_chain(2, a5, b5, c5, big, ts5))
             reps = keep
             alg5 = units * algorithmic_bytes(big, LR, LR, UNITS, BLOCKS, SCALE, s)["sr_wdsr_block_fwd"]
-            roofline["batch512"] = {"avg_launch_us": round(us5, 2), "achieved": round(alg5 / (us5 * 1e-6) / 1e9, 1),
-                                    "frac": round(alg5 / (us5 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
-            del a5, b5, c5
+            # one whole image per workgroup: the streaming kernel (csrc/wdsr_fwd_stream.h), 4 464 MFMAs per image and two blocks
+            floor5 = 4464 * (big / 256) / 4 * 32 / 2.4e3
+            roofline["batch512"] = {"kernel": "wdsr_fwd_stream_kernel<24,144,20,false>", "avg_launch_us": round(us5, 2),
+                                    "achieved": round(alg5 / (us5 * 1e-6) / 1e9, 1),
+                                    "frac": round(alg5 / (us5 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "mfma_floor_us": round(floor5, 2),
+                                    "mfma_frac": round(floor5 / us5, 4),
+                                    "training_variant": {"kernel": "wdsr_fwd_stream_kernel<24,144,20,true>", "avg_launch_us": round(us5s, 2),
+                                                         "frac": round(alg5 / (us5s * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
+            del a5, b5, c5, ts5
         else:
             roofline["bound"] = "hbm"
         kernels = {"call_us": calls}

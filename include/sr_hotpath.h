@@ -74,9 +74,11 @@ int sr_wdsr_block_wgrad_saved(const void* x, const void* dy, const void* tsave, 
 int sr_wdsr_fwd_rs(const void* x, void* ya, void* yb, const void* wblob_a, const void* wblob_b, const float* cinit_a,
                    const float* cinit_b, void* tsave_a, void* tsave_b, int nblk, int N, int H, int W, int F, int dtype,
                    sr_stream_t stream);
+/* measurement aid: `reps` back-to-back launches ping-ponging x <-> yb; tsave_a / tsave_b as in sr_wdsr_fwd_rs (NULL: the
+ * inference variant; both given: the variant a training step launches, which also keeps the t images) */
 int sr_wdsr_fwd_rs_repeat(void* x, void* ya, void* yb, const void* wblob_a, const void* wblob_b, const float* cinit_a,
-                          const float* cinit_b, int nblk, int N, int H, int W, int F, int dtype, int reps,
-                          sr_stream_t stream);
+                          const float* cinit_b, void* tsave_a, void* tsave_b, int nblk, int N, int H, int W, int F, int dtype,
+                          int reps, sr_stream_t stream);
 
 /* Measurement aid for bench.py's roofline leg: `reps` back-to-back launches of the same forward kernel,
  * ping-ponging x <-> y, so that HIP events around the call measure the kernel and not the host. */

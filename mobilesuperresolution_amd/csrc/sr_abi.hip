@@ -18,7 +18,7 @@
 #include "train_step.h"
 #include "pixel_shuffle.h"
 
-extern "C" int sr_abi_version(void) { return 9; }
+extern "C" int sr_abi_version(void) { return 10; }
 
 namespace {
 
@@ -86,11 +86,11 @@ static int launch_fwd_rs(const void* x, void* ya, void* yb, const void* wa, cons
     // (csrc/wdsr_fwd_stream.h: no halo recompute, one barrier per band), with or without the saved t images
     if (fwd_stream_applies(N, H, W)) {
       if (tsa && tsb)
-        hipLaunchKernelGGL((wdsr_fwd_stream_kernel<F, E, L, true>), dim3(N), dim3(512), 0, st, (const T*)x, (T*)ya, (T*)yb, (const T*)wa,
-                           (const T*)wb, cia, cib, (T*)tsa, (T*)tsb, H);
+        hipLaunchKernelGGL((wdsr_fwd_stream_kernel<F, E, L, true>), dim3(256), dim3(512), 0, st, (const T*)x, (T*)ya, (T*)yb, (const T*)wa,
+                           (const T*)wb, cia, cib, (T*)tsa, (T*)tsb, N, H);
       else
-        hipLaunchKernelGGL((wdsr_fwd_stream_kernel<F, E, L, false>), dim3(N), dim3(512), 0, st, (const T*)x, (T*)ya, (T*)yb, (const T*)wa,
-                           (const T*)wb, cia, cib, (T*)nullptr, (T*)nullptr, H);
+        hipLaunchKernelGGL((wdsr_fwd_stream_kernel<F, E, L, false>), dim3(256), dim3(512), 0, st, (const T*)x, (T*)ya, (T*)yb, (const T*)wa,
+                           (const T*)wb, cia, cib, (T*)nullptr, (T*)nullptr, N, H);
       SR_HIP_CHECK_LAUNCH();
       return 0;
     }
@@ -144,11 +144,11 @@ extern "C" int sr_wdsr_block2_fwd(const void* x, void* ya, void* yb, const void*
   return sr_wdsr_fwd_rs(x, ya, yb, wa, wb, cia, cib, tsa, tsb, 2, N, H, W, F, dtype, stream);
 }
 extern "C" int sr_wdsr_fwd_rs_repeat(void* x, void* ya, void* yb, const void* wa, const void* wb, const float* cia,
-                                     const float* cib, int nblk, int N, int H, int W, int F, int dtype, int reps,
-                                     sr_stream_t stream) {
+                                     const float* cib, void* tsa, void* tsb, int nblk, int N, int H, int W, int F, int dtype,
+                                     int reps, sr_stream_t stream) {
   for (int i = 0; i < reps; ++i) {
-    const int rc = (i & 1) ? sr_wdsr_fwd_rs(yb, ya, x, wa, wb, cia, cib, nullptr, nullptr, nblk, N, H, W, F, dtype, stream)
-                           : sr_wdsr_fwd_rs(x, ya, yb, wa, wb, cia, cib, nullptr, nullptr, nblk, N, H, W, F, dtype, stream);
+    const int rc = (i & 1) ? sr_wdsr_fwd_rs(yb, ya, x, wa, wb, cia, cib, tsa, tsb, nblk, N, H, W, F, dtype, stream)
+                           : sr_wdsr_fwd_rs(x, ya, yb, wa, wb, cia, cib, tsa, tsb, nblk, N, H, W, F, dtype, stream);
     if (rc) return rc;
   }
   return 0;

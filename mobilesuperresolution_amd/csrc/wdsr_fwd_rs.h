@@ -380,8 +380,9 @@ SR_DEV void rw_store_y(const f32x16& oacc, const RwPixB& p, __bf16* Xnext, __amd
   if (to_global) {
     const unsigned off = p.go + hh * 8;
 #pragma unroll
-    for (int g = 0; g < C::FC; ++g)
+    for (int g = 0; g < C::FC; ++g) {
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, v[g]), yrs, off + g * 16, 0, 2 /* nt */);
+    }
   }
 }
 

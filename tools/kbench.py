@@ -55,7 +55,7 @@ for batch in [int(b) for b in args.batches.split(",")]:
         row.update({"fwd2_us": round(u2 * 1e6, 2), "fwd2_GBs": round(2 * alg / u2 / 1e9), "fwd2_frac": round(2 * alg / u2 / 8e12, 4)})
     for nblk in ((1, 2) if F == 24 else (1,)):
         fr = lambda: L.check(lib.sr_wdsr_fwd_rs_repeat(a.data_ptr(), b1.data_ptr(), b2.data_ptr(), st.blob_body[0].data_ptr(),
-                             st.blob_body[1].data_ptr(), st.cinit_body[0].data_ptr(), st.cinit_body[1].data_ptr(), nblk, batch, 48, 48,
+                             st.blob_body[1].data_ptr(), st.cinit_body[0].data_ptr(), st.cinit_body[1].data_ptr(), None, None, nblk, batch, 48, 48,
                              F, 1, reps, L.stream_ptr()), "rs")
         u = ev_time(fr) / reps
         row.update({f"rs{nblk}_us": round(u * 1e6, 2), f"rs{nblk}_frac": round(nblk * alg / u / 8e12, 4)})
