@@ -170,6 +170,23 @@ def main():
         opt.step()
         return loss
 
+    # the reference's loop UNCHANGED (pretrain.py:69-82) with its two objects swapped for the library's drop-ins
+    # (mobilesuperresolution_amd.training.L1Loss / .Adam): forward, criterion, backward, optimizer.step, loss.item()
+    from mobilesuperresolution_amd import training as T
+    crit_ref = T.L1Loss()
+    opt_ref = T.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr_rate)
+
+    def step_reference_surface():
+        opt_ref.zero_grad()
+        sr = net(x)
+        loss = 0
+        loss_sr_l1 = 1.0 * crit_ref(sr, hr)
+        loss += loss_sr_l1
+        loss.backward()
+        opt_ref.step()
+        opt_ref.zero_grad()
+        return loss.item()
+
     fused = not wrapper                                  # the library's own step (one rank: one call; N ranks: + 2 all-reduces)
     state = model.make_train_state(lr=lr_rate) if fused else None
 
@@ -218,11 +235,14 @@ def main():
     nd = max(args.steps, 50)
     dist_ms = per_step_ms(step, nd)
     item_ms = wall_ms(lambda: step().item(), nd)
-    unfused_ms = None
+    unfused_ms = ref_surface_ms = None
     if fused and not use_ddp:
         for _ in range(5):                               # (torch's optimizer initialises its state on first use)
             step_unfused()
         unfused_ms = wall_ms(step_unfused, nd)
+        for _ in range(5):
+            step_reference_surface()
+        ref_surface_ms = wall_ms(step_reference_surface, nd)
 
     # forward-only (inference) throughput, same batch
     model.eval()
@@ -378,6 +398,9 @@ def main():
                             "p90": round(dist_ms[(nd * 9) // 10], 4)},
             "ms_per_step_with_item_sync": round(item_ms, 4),
             "unfused_ms_per_step": None if unfused_ms is None else round(unfused_ms, 4),
+            "reference_surface_ms_per_step": None if ref_surface_ms is None else round(ref_surface_ms, 4),
+            "reference_surface": "pretrain.py:69-82 verbatim (zero_grad / model(lr) / criterion / backward / optimizer.step / "
+                                 "loss.item() every step) with nn.L1Loss -> training.L1Loss and optim.Adam -> training.Adam",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"WDSR-B x{SCALE}, {BLOCKS} blocks / {UNITS} units, {LR}x{LR} LR patches, "
                                    f"batch {BATCH} per GPU, fwd+L1+bwd+Adam" + (f", DDP/{'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()}" if use_ddp else ""),

@@ -1,0 +1,144 @@
+"""Drop-ins for the two torch objects the reference trainers build next to the model, so that their training loops run
+UNCHANGED on the fast route:
+
+    pretrain.py:137      optim.Adam(filter(...model.parameters()), lr)        ->  training.Adam(...)
+    pretrain.py:220      criterions = {'l1': nn.L1Loss()}                      ->  {'l1': training.L1Loss()}
+    train_video_superresolution.py:43-53   L1_Charbonnier_loss()              ->  training.L1_Charbonnier_loss()
+
+and then, as before (pretrain.py:69-82):
+
+    optimizer.zero_grad(); sr = model(lr); loss = w * criterions['l1'](sr, hr); loss.backward(); optimizer.step(); loss.item()
+
+What changes underneath.  `criterion(sr, hr)` recognises an `sr` that came straight out of BASIC_MODEL.forward (its grad_fn is
+the network's autograd node) and runs the network's backward right there with the loss folded into the tail-backward kernel
+(csrc/wdsr_ends.h, sr_tail_bwd_loss): no d(loss)/d(sr) tensor, none of the seven small ATen loss kernels; `loss.backward()` then
+only hands the finished parameter gradient over (scaled by whatever the trainer multiplied the loss with).  `Adam.step()` is ONE
+launch of the library's Adam kernel per parameter tensor (BASIC_MODEL has one flat parameter) with torch.optim.Adam's
+arithmetic bit for bit (tests/test_gpu_train_step.py), where torch's multi-tensor path takes ~43 us for it.  Any other tensor
+(`sr` from another module, a sliced `sr`, no grad mode) takes torch's own ops: that is the reference's behaviour, not a fallback
+of the hot path."""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+__all__ = ["L1Loss", "L1_Charbonnier_loss", "Adam"]
+
+
+def _network_node(sr: torch.Tensor):
+    """the BASIC_MODEL autograd node that produced `sr`, or None"""
+    fn = sr.grad_fn
+    if fn is None or type(fn).__name__ != "_NetFunctionBackward" or not hasattr(fn, "model"):
+        return None
+    return fn
+
+
+class _FoldedCriterion(torch.autograd.Function):
+    """loss(sr, hr) where sr = BASIC_MODEL(x): forward() runs the network's BACKWARD with the loss gradient formed inside the
+    tail-backward kernel and returns the loss value; backward() parks the parameter gradient on the network's node and sends a
+    zero-stride zero token up the graph in place of d(loss)/d(sr)."""
+
+    @staticmethod
+    def forward(ctx, sr, hr, node, kind):
+        model = node.model
+        gflat, keep = model._backward_folded(node, sr, hr, kind)
+        st = model._state(sr.device)
+        loss = torch.empty((), dtype=torch.float32, device=sr.device)
+        with torch.cuda.device(sr.device):
+            L.launch("sr_loss_value", L.lib().sr_loss_value, st.loss_part.data_ptr(), st.wgs_tail, 1.0 / sr.numel(), loss.data_ptr(),
+                     L.stream_ptr(sr.device))
+        ctx.node = node
+        ctx.token = torch.zeros(1, dtype=sr.dtype, device=sr.device).expand(sr.shape)
+        ctx.save_for_backward(gflat)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (gflat,) = ctx.saved_tensors
+        ctx.node.folded = (gflat, gloss, ctx.token.data_ptr())
+        return ctx.token, None, None, None
+
+
+class _HotLoss(nn.Module):
+    KIND = "l1"
+
+    def forward(self, sr: torch.Tensor, hr: torch.Tensor) -> torch.Tensor:
+        node = _network_node(sr) if (torch.is_grad_enabled() and sr.requires_grad) else None
+        if node is None or getattr(node, "folded", None) is not None or not node.model._can_fold(node, sr, hr):
+            return self._torch_loss(sr, hr)
+        return _FoldedCriterion.apply(sr, hr.detach().contiguous().float(), node, self.KIND)
+
+
+class L1Loss(_HotLoss):
+    """nn.L1Loss() (mean reduction) -- pretrain.py:220 / :73"""
+    KIND = "l1"
+
+    def _torch_loss(self, sr, hr):
+        return torch.nn.functional.l1_loss(sr, hr)
+
+
+class L1_Charbonnier_loss(_HotLoss):
+    """train_video_superresolution.py:43-53: mean(sqrt((X - Y)^2 + 1e-12))"""
+    KIND = "charbonnier"
+
+    def __init__(self):
+        super().__init__()
+        self.eps = 1e-12
+
+    def _torch_loss(self, sr, hr):
+        diff = torch.add(sr, -hr)
+        return torch.mean(torch.sqrt(diff * diff + self.eps))
+
+
+class Adam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr, betas, eps) with the step of every parameter tensor as ONE launch of csrc/train_step.h's
+    adam_step_kernel (same fused-multiply-add forms as torch's foreach implementation: parameters bit-identical).  State keys
+    are torch's (`step`, `exp_avg`, `exp_avg_sq`), so optimizer checkpoints interchange (pretrain.py:262-267); schedulers
+    (MultiStepLR, pretrain.py:139-142) act on `param_groups[i]['lr']` as usual.  weight_decay / amsgrad / maximize: not on the
+    reference's path, rejected."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if weight_decay != 0 or amsgrad:
+            raise NotImplementedError("training.Adam mirrors the reference's optim.Adam(params, lr): no weight decay, no amsgrad")
+        if not 0.0 <= lr or not 0.0 <= eps or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
+            raise ValueError("invalid Adam hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = L.lib()
+        for group in self.param_groups:
+            lr, (b1, b2), eps = float(group["lr"]), group["betas"], float(group["eps"])
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                g = p.grad
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or g.dtype != torch.float32 or g.is_sparse:
+                    raise L.HotpathError("training.Adam steps contiguous fp32 CUDA parameters (there is no CPU fallback)")
+                g = g.contiguous()
+                state = self.state[p]
+                if len(state) == 0:
+                    state["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state["step"] += 1
+                t = int(state["step"])
+                bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
+                scal = L.AdamScalars(1.0 - b1, b2, 1.0 - b2, math.sqrt(bc2), eps, -(lr / bc1))
+                with torch.cuda.device(p.device):
+                    L.launch("sr_adam_step", lib.sr_adam_step, p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(),
+                             state["exp_avg_sq"].data_ptr(), p.numel(), ctypes.byref(scal), None, 0, 0.0, None, L.stream_ptr(p.device))
+                try:
+                    torch.autograd.graph.increment_version(p)
+                except AttributeError:
+                    p.add_(0)
+        return loss

@@ -119,3 +119,82 @@ def test_backward_after_interleaved_forward_repacks():
         m.flat.add_(0.01)                                      # "optimizer step" between forward and backward
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
         y.sum().backward()
+
+
+# ---- the reference trainers' own loop on the fast route: training.L1Loss / L1_Charbonnier_loss + training.Adam ----
+def _reference_loop(model, opt, crit, x, hr, steps, weight=1.0):
+    """pretrain.py:69-82, verbatim in structure"""
+    losses = []
+    for _ in range(steps):
+        opt.zero_grad()
+        sr = model(x)
+        loss = 0
+        loss_sr_l1 = weight * crit(sr, hr)
+        loss += loss_sr_l1
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        losses.append(loss.item())
+    return losses
+
+
+@pytest.mark.parametrize("kind", ["l1", "charbonnier"])
+def test_reference_training_loop_with_drop_in_loss_and_adam_is_bit_identical(kind):
+    """the reference's loop with the two swapped imports (mobilesuperresolution_amd.training) against the same loop with
+    torch's nn.L1Loss / the reference's Charbonnier module and torch.optim.Adam: bf16 mode, same kernels underneath, so the
+    parameters agree bit for bit after every step; the loss values to fp32 rounding"""
+    from mobilesuperresolution_amd import training as T
+    from mobilesuperresolution_amd.models import get_model
+    torch.manual_seed(3)
+    a = get_model(_ns("bf16", nb=4)).cuda().train()
+    b = get_model(_ns("bf16", nb=4)).cuda().train()
+    b.load_state_dict(a.state_dict(), strict=True)
+    x = torch.rand(4, 3, 24, 24, device="cuda")
+    hr = torch.rand(4, 3, 96, 96, device="cuda")
+    crit_t = torch.nn.L1Loss() if kind == "l1" else (lambda s, h: _charbonnier(s, h))
+    crit_h = T.L1Loss() if kind == "l1" else T.L1_Charbonnier_loss()
+    opt_t = torch.optim.Adam(filter(lambda p: p.requires_grad, a.parameters()), 1e-3)
+    opt_h = T.Adam(filter(lambda p: p.requires_grad, b.parameters()), 1e-3)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt_h, milestones=[2], gamma=0.3)       # pretrain.py:139-142
+    sched_t = torch.optim.lr_scheduler.MultiStepLR(opt_t, milestones=[2], gamma=0.3)
+    for epoch in range(4):
+        lt = _reference_loop(a, opt_t, crit_t, x, hr, 2, weight=0.5)
+        lh = _reference_loop(b, opt_h, crit_h, x, hr, 2, weight=0.5)
+        sched.step()
+        sched_t.step()
+        for u, v in zip(lt, lh):
+            assert abs(u - v) <= 2e-6 * abs(u) + 1e-7
+        if kind == "l1":
+            assert torch.equal(a.flat.detach(), b.flat.detach()), f"parameters differ after epoch {epoch}"
+        else:
+            assert float((a.flat.detach() - b.flat.detach()).abs().max()) <= 2e-5
+    sd = opt_h.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 8.0
+    opt_h2 = T.Adam(b.parameters(), 1e-3)
+    opt_h2.load_state_dict(sd)                                  # checkpoint round trip (pretrain.py:262-267)
+    assert torch.equal(opt_h2.state[b.flat]["exp_avg"], opt_h.state[b.flat]["exp_avg"])
+
+
+def test_drop_in_loss_other_uses_of_the_output_still_work():
+    """a second, ordinary use of `sr` next to the folded criterion (gradient = folded + usual backward), a criterion on a
+    detached / foreign tensor (torch's own ops), and eval mode"""
+    from mobilesuperresolution_amd import training as T
+    from mobilesuperresolution_amd.models import get_model
+    torch.manual_seed(4)
+    m = get_model(_ns("bf16", nb=2)).cuda().train()
+    x = torch.rand(2, 3, 20, 28, device="cuda")
+    hr = torch.rand(2, 3, 80, 112, device="cuda")
+    crit = T.L1Loss()
+    sr = m(x)
+    (crit(sr, hr) + 0.1 * sr.mean()).backward()
+    g = m.flat.grad.clone()
+    m.flat.grad = None
+    sr = m(x)
+    (torch.nn.functional.l1_loss(sr, hr) + 0.1 * sr.mean()).backward()
+    ref = m.flat.grad
+    assert float((g - ref).abs().max()) <= 5e-3 * float(ref.abs().max())        # (bf16: the two gradients are rounded separately)
+    assert float((g - ref).norm()) <= 2e-3 * float(ref.norm())
+    assert float(crit(sr.detach(), hr)) == pytest.approx(float(torch.nn.functional.l1_loss(sr.detach(), hr)), rel=1e-6)
+    with torch.no_grad():
+        m.eval()
+        assert float(crit(m(x), hr)) > 0
