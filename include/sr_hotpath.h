@@ -364,6 +364,15 @@ int sr_loss_value(const float* loss_part, int n_loss, float loss_scale, float* l
 int sr_wdsr_net_train_step(const sr_wdsr_net_t* net, float* exp_avg, float* exp_avg_sq, long n_params, const sr_adam_t* a,
                            float loss_scale, float* loss_out, sr_stream_t stream);
 
+/* ---- SPyNet's 7x7 convolutions (models/spynet_arch.py:17-22), bf16 activations NHWC ----
+ * y[n, h, w, co] = act(bias[co] + sum_{ky, kx, ci} w[co, ci, ky, kx] x[n, h + ky - 3, w + kx - 3, ci]), zero padding.
+ * x: [N][H][W][CIN] bf16; wpacked: the layer's weights as MFMA fragments [7 ky][k-step][32-row tile][64 lanes][8] bf16 (k-step =
+ * (kx, 16 input channels), for CIN = 8: two adjacent taps; packing.conv7_pack builds it); bias: [ceil(COUT / 32) * 32] fp32;
+ * y: [N][H][W][COUT] bf16, or fp32 when out_f32.  Supported (CIN, COUT, relu, out_f32): (8,32,1,0) (32,64,1,0) (64,32,1,0)
+ * (32,16,1,0) (16,2,0,1) -- the five layers of a BasicModule; anything else returns -1. */
+int sr_conv7_fwd(const void* x, const void* wpacked, const float* bias, void* y, int N, int H, int W, int CIN, int COUT, int relu,
+                 int out_f32, sr_stream_t stream);
+
 /* ---- hardware probes used by tests/test_gpu_probe.py (lane maps the kernels rely on) ---- */
 int sr_probe_mfma_bf16(const void* a_frag, const void* b_frag, float* acc_out, sr_stream_t stream);
 int sr_probe_mfma_f32(const float* a_frag, const float* b_frag, float* acc_out, sr_stream_t stream);

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SR_HOTPATH_LIB_PATH (tools/ only): an explicitly named build of the same sources (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("SR_HOTPATH_LIB_PATH") or os.path.join(
     _HERE, "libsr_hotpath_dbg.so" if os.environ.get("SR_HOTPATH_DEBUG_LIB") == "1" else "libsr_hotpath.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
 
 _P, _I, _Z, _L, _F = c_void_p, c_int, c_size_t, ctypes.c_long, ctypes.c_float
@@ -23,6 +23,7 @@ SIGNATURES = {
     "sr_wdsr_block_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block2_fwd": ([_P] * 9 + [_I] * 5 + [_P], _I),
     "sr_wdsr_fwd_rs": ([_P] * 9 + [_I] * 6 + [_P], _I),
+    "sr_conv7_fwd": ([_P] * 4 + [_I] * 7 + [_P], _I),
     "sr_wdsr_fwd_rs_repeat": ([_P] * 9 + [_I] * 7 + [_P], _I),
     "sr_wdsr_block_wgrad_saved": ([_P] * 8 + [_I] * 7 + [_L] * 5 + [_P], _I),
     "sr_wdsr_block2_bwd_data": ([_P] * 11 + [_I] * 5 + [_P], _I),

@@ -9,6 +9,7 @@
 #include "wdsr_ends.h"
 #include "wdsr_prep.h"
 #include "conv3x3.h"
+#include "spynet_conv.h"
 #include "nas_block.h"
 #include "nas_dw_lc.h"
 #include "nas_bwd_fused.h"
@@ -18,7 +19,7 @@
 #include "train_step.h"
 #include "pixel_shuffle.h"
 
-extern "C" int sr_abi_version(void) { return 10; }
+extern "C" int sr_abi_version(void) { return 11; }
 
 namespace {
 
@@ -1355,4 +1356,26 @@ extern "C" int sr_debug_set_stamps(void* buf, long n_workgroups) {
   (void)buf; (void)n_workgroups;
   return -1;
 #endif
+}
+
+// ---- SPyNet's 7x7 convolutions (csrc/spynet_conv.h) ----
+template <int CIN, int COUT, bool RELU, bool OUT_F32>
+static int launch_conv7(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, hipStream_t st) {
+  typedef Conv7Cfg<CIN, COUT> K;
+  const int tiles_x = (W + K::TW - 1) / K::TW, tiles_y = (H + K::TH - 1) / K::TH;
+  hipLaunchKernelGGL((conv7_fwd_kernel<CIN, COUT, RELU, OUT_F32>), dim3(tiles_x * tiles_y, N), dim3(512), 0, st, (const __bf16*)x,
+                     (const __bf16*)w, bias, y, H, W, tiles_x);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int sr_conv7_fwd(const void* x, const void* wpacked, const float* bias, void* y, int N, int H, int W, int CIN, int COUT,
+                            int relu, int out_f32, sr_stream_t stream) {
+  if (!x || !wpacked || !bias || !y || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  if (CIN == 8 && COUT == 32 && relu && !out_f32) return launch_conv7<8, 32, true, false>(x, wpacked, bias, y, N, H, W, st);
+  if (CIN == 32 && COUT == 64 && relu && !out_f32) return launch_conv7<32, 64, true, false>(x, wpacked, bias, y, N, H, W, st);
+  if (CIN == 64 && COUT == 32 && relu && !out_f32) return launch_conv7<64, 32, true, false>(x, wpacked, bias, y, N, H, W, st);
+  if (CIN == 32 && COUT == 16 && relu && !out_f32) return launch_conv7<32, 16, true, false>(x, wpacked, bias, y, N, H, W, st);
+  if (CIN == 16 && COUT == 2 && !relu && out_f32) return launch_conv7<16, 2, false, true>(x, wpacked, bias, y, N, H, W, st);
+  return -1;
 }

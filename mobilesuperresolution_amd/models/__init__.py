@@ -6,14 +6,14 @@ from __future__ import annotations
 import argparse
 
 from .basic_wdsr_b import BASIC_MODEL
-from .basicvsr_arch import ConvResidualBlocks, ResidualBlockNoBN
+from .basicvsr_arch import BasicVSR, ConvResidualBlocks, ResidualBlockNoBN
 from .basicvsr_arch_origin import BasicVSR_origin, pixel_shuffle
 from .mvvsr_arch import MotionVectorVSR
-from .spynet_arch import flow_warp
+from .spynet_arch import SpyNet, flow_warp
 from .wdsr_b import NAS_MODEL, ModelOutput
 
 __all__ = ["BASIC_MODEL", "NAS_MODEL", "ModelOutput", "ConvResidualBlocks", "ResidualBlockNoBN", "MotionVectorVSR",
-           "BasicVSR_origin", "flow_warp", "pixel_shuffle", "get_model", "update_argparser", "wrap_ddp"]
+           "BasicVSR_origin", "BasicVSR", "SpyNet", "flow_warp", "pixel_shuffle", "get_model", "update_argparser", "wrap_ddp"]
 
 _REGISTRY = {"BASIC_MODEL": BASIC_MODEL, "NAS_MODEL": NAS_MODEL}
 

@@ -30,7 +30,7 @@ import torch.nn.functional as F
 from .. import _lib as L
 from .. import packing as P
 
-__all__ = ["ConvResidualBlocks", "ResidualBlockNoBN", "propagate"]
+__all__ = ["BasicVSR", "ConvResidualBlocks", "ResidualBlockNoBN", "propagate"]
 
 _DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16}
 
@@ -472,3 +472,60 @@ def propagate(x, flows_forward, flows_backward, backward_trunk, forward_trunk, f
         feat = forward_trunk(torch.cat([x[:, i], feat], dim=1))
         out_f.append(feat)
     return out_b, out_f
+
+
+class BasicVSR(nn.Module):
+    """The trainer's 'basic' model (reference: models/basicvsr_arch.py:10-105; constructed at
+    train_video_superresolution.py:249 as BasicVSR(num_feat=24, num_block=8, spynet_path=...)).
+
+    Same constructor, same submodules in the same order (so a seeded init and the state_dict keys agree; `spynet.*` follows
+    the vendored models/spynet_arch.py naming -- the reference imports mmedit's SPyNet here, which is not in the repository),
+    `.scale`, `get_flow` and `forward(x, height, weight)`: SpyNet flows (MFMA kernels) -> the two recurrent propagation loops
+    (HIP, warp + concat gathered into the first conv) -> fusion -> conv_last -> bilinear resize -> `out += base`.  The last
+    statement fails in the REFERENCE as well: conv_last is ConvTranspose2d(2F -> F), so `out` has F channels and `base` three
+    (basicvsr_arch.py:36,96-100; SURVEY section 0: "RuntimeError: size of tensor a (24) must match b (3)"); conv_hr (F -> 3) is
+    defined and never called.  The same statement is kept, so the same error is raised -- after the propagation half, which is
+    what `propagation_features` exposes for use and for the parity tests."""
+
+    def __init__(self, num_feat=64, num_block=15, spynet_path=None, hot_dtype=None):
+        super().__init__()
+        from .spynet_arch import SpyNet
+        self.num_feat = num_feat
+        self.spynet = SpyNet(spynet_path)
+        self.scale = 4
+        self.backward_trunk = ConvResidualBlocks(num_feat + 3, num_feat, num_block, hot_dtype=hot_dtype)
+        self.forward_trunk = ConvResidualBlocks(num_feat + 3, num_feat, num_block, hot_dtype=hot_dtype)
+        self.fusion = nn.Conv2d(num_feat * 2, num_feat * 2, 1, 1, 0, bias=True)
+        self.upconv1 = nn.Conv2d(num_feat, num_feat * 4, 3, 1, 1, bias=True)
+        self.upconv2 = nn.Conv2d(num_feat, num_feat * 4, 3, 1, 1, bias=True)
+        self.conv_last = nn.ConvTranspose2d(num_feat * 2, num_feat, 5, stride=self.scale)
+        self.conv_hr = nn.Conv2d(num_feat, 3, 3, 1, 1)
+        self.pixel_shuffle = nn.PixelShuffle(2)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
+
+    def get_flow(self, x):
+        b, n, c, h, w = x.size()
+        x_1 = x[:, :-1, :, :, :].reshape(-1, c, h, w)
+        x_2 = x[:, 1:, :, :, :].reshape(-1, c, h, w)
+        flows_backward = self.spynet(x_1, x_2).view(b, n - 1, 2, h, w)
+        flows_forward = self.spynet(x_2, x_1).view(b, n - 1, 2, h, w)
+        return flows_forward, flows_backward
+
+    def propagation_features(self, x, flows=None):
+        """(backward features, forward features) per frame: basicvsr_arch.py:67-88 without the reconstruction"""
+        from .spynet_arch import flow_warp
+        flows_forward, flows_backward = flows if flows is not None else self.get_flow(x)
+        return propagate(x, flows_forward, flows_backward, self.backward_trunk, self.forward_trunk, flow_warp, num_feat=self.num_feat)
+
+    def forward(self, x, height=1080, weight=1920):
+        feat_b, feat_f = self.propagation_features(x)
+        out_l = []
+        for i in range(x.size(1)):
+            out = torch.cat([feat_b[i], feat_f[i]], dim=1)
+            out = self.lrelu(self.fusion(out))
+            out = self.conv_last(out)
+            out = nn.functional.interpolate(out, size=(height, weight), mode='bilinear')
+            base = nn.functional.interpolate(x[:, i], size=(height, weight), mode='bilinear', align_corners=False)
+            out += base                              # (F channels += 3 channels: raises, as in the reference)
+            out_l.append(out)
+        return torch.stack(out_l, dim=1)

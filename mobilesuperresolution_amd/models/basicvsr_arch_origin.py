@@ -5,10 +5,10 @@ MotionVectorVSR's, and the two PixelShuffle(2) stages of the upsampler (:37,87-8
 shuffle (csrc/pixel_shuffle.h, bit-exact).  The upsampler's convolutions (upconv1/2, conv_hr, conv_last) and the
 bilinear base are plain library convolutions in the reference and stay in ATen.
 
-SPyNet (the reference's flow estimate, `get_flow`, :42-51) is out of scope: flows are GIVEN, either
-as `forward(x, height, weight, flows=(flows_forward, flows_backward))` with (b, n-1, 2, h, w) tensors, or -- as
-MotionVectorVSR takes them -- as motion-vector channels 3..4 of a 5-channel input.  A 3-channel input without flows
-raises.  `spynet.*` keys of a reference checkpoint are accepted and ignored."""
+Flows: `get_flow` (:42-51) runs SpyNet on every adjacent frame pair in both directions, as the reference does; SpyNet's 7x7
+convolutions are MFMA kernels (models/spynet_arch.py, csrc/spynet_conv.h; inference only -- the reference's trainer keeps SPyNet
+out of the optimizer).  Flows may also be GIVEN: `forward(x, height, weight, flows=(flows_forward, flows_backward))` with
+(b, n-1, 2, h, w) tensors, or -- as MotionVectorVSR takes them -- as motion-vector channels 3..4 of a 5-channel input."""
 from __future__ import annotations
 
 import torch
@@ -17,8 +17,7 @@ from torch.nn import functional as F
 
 from .. import _lib as L
 from .basicvsr_arch import ConvResidualBlocks, propagate
-from .mvvsr_arch import _IgnoresSpynetKeys
-from .spynet_arch import flow_warp
+from .spynet_arch import SpyNet, flow_warp
 
 __all__ = ["BasicVSR_origin", "pixel_shuffle"]
 
@@ -55,11 +54,12 @@ def pixel_shuffle(x: torch.Tensor, r: int) -> torch.Tensor:
     return _PixelShuffle.apply(x.contiguous().float(), int(r))
 
 
-class BasicVSR_origin(_IgnoresSpynetKeys, nn.Module):
+class BasicVSR_origin(nn.Module):
 
     def __init__(self, num_feat=64, num_block=15, spynet_path=None, hot_dtype=None):
         super().__init__()
         self.num_feat = num_feat
+        self.spynet = SpyNet(spynet_path)            # alignment (basicvsr_arch_origin.py:25)
         self.scale = 4
         self.backward_trunk = ConvResidualBlocks(num_feat + 3, num_feat, num_block, hot_dtype=hot_dtype)
         self.forward_trunk = ConvResidualBlocks(num_feat + 3, num_feat, num_block, hot_dtype=hot_dtype)
@@ -72,8 +72,13 @@ class BasicVSR_origin(_IgnoresSpynetKeys, nn.Module):
         self.lrelu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
 
     def get_flow(self, x):
-        raise NotImplementedError("SPyNet (the reference's optical-flow prior) is out of scope of the MI355X hot path: pass "
-                                  "flows=(flows_forward, flows_backward) or a 5-channel input with motion vectors")
+        """basicvsr_arch_origin.py:42-51"""
+        b, n, c, h, w = x.size()
+        x_1 = x[:, :-1, :, :, :].reshape(-1, c, h, w)
+        x_2 = x[:, 1:, :, :, :].reshape(-1, c, h, w)
+        flows_backward = self.spynet(x_1, x_2).view(b, n - 1, 2, h, w)
+        flows_forward = self.spynet(x_2, x_1).view(b, n - 1, 2, h, w)
+        return flows_forward, flows_backward
 
     def forward(self, x, height, weight, flows=None):
         if flows is None:

@@ -549,3 +549,33 @@ def nas_prep_tables(F: int, nb: int, layout, blocks=None):
     return dict(chan_tab=chan_tab, bias_tab=bias_tab, chan_bwd=i32(chan_bwd), bias_bwd=i32(bias_bwd), pw_sidx=i32(pw_sidx),
                 pw_dst=i32(pw_dst), dw_sidx=i32(dw_sidx), dw_dst=i32(dw_dst), size=size, ds=ds, extra=ex, off=o)
 
+
+
+# =====================================================================================
+# SPyNet's 7x7 convolutions (reference: models/spynet_arch.py:17-22) -> csrc/spynet_conv.h
+# =====================================================================================
+@lru_cache(maxsize=None)
+def conv7_tables(cin: int, cout: int):
+    """Gather table for one 7x7 layer: packed = src[idx] with src = weight (cout, cin, 7, 7).reshape(-1) | 0.0, laid out as the
+    kernel consumes it: [ky][k-step][32-row tile][lane][8].  k-step s (cin >= 16) = (tap kx = s // (cin/16), channels
+    16 (s % (cin/16)) + 8 hh + j); cin = 8: two adjacent taps per k-step, kx = 2 s + hh (kx = 7: zero), channel j."""
+    assert cin == 8 or cin % 16 == 0
+    mt = (cout + 31) // 32
+    kpr = 4 if cin == 8 else 7 * (cin // 16)
+    zero = cout * cin * 49
+    ky = np.arange(7).reshape(7, 1, 1, 1, 1)
+    s = np.arange(kpr).reshape(1, kpr, 1, 1, 1)
+    m = np.arange(mt).reshape(1, 1, mt, 1, 1)
+    lane = np.arange(64).reshape(1, 1, 1, 64, 1)
+    j = np.arange(8).reshape(1, 1, 1, 1, 8)
+    ky, s, m, lane, j = np.broadcast_arrays(ky, s, m, lane, j)
+    r, hh = lane & 31, lane >> 5
+    co = 32 * m + r
+    if cin == 8:
+        kx, ci = 2 * s + hh, j
+    else:
+        cc = cin // 16
+        kx, ci = s // cc, 16 * (s % cc) + 8 * hh + j
+    ok = (co < cout) & (kx < 7)
+    idx = np.where(ok, ((np.minimum(co, cout - 1) * cin + ci) * 7 + ky) * 7 + np.minimum(kx, 6), zero)
+    return dict(idx=idx.reshape(-1).astype(np.int64), mt=mt, kpr=kpr)

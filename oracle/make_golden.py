@@ -379,6 +379,34 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from set5_like import SET5_SHAPES, set5_like_hr  # noqa: E402
 
 
+def g15_spynet():
+    """G15: the reference's vendored SpyNet (models/spynet_arch.py:28-96) at its seeded default init (torch.manual_seed(150); 1.44 M
+    parameters are re-created from the seed by the tests, checksums stored) on two frame pairs: 64 x 64 (C4's size) and
+    40 x 56 (resized to 64 x 64 inside, flows scaled back).  Stored: inputs, output flows, per-level module outputs of pair 0."""
+    sys.path.insert(0, REF)
+    import importlib
+    sp = importlib.import_module("models.spynet_arch")
+    torch.manual_seed(150)
+    net = sp.SpyNet().eval()
+    d = {"w_sum": np.float64(sum(v.double().sum().item() for k, v in net.state_dict().items())),
+         "w_abs": np.float64(sum(v.double().abs().sum().item() for k, v in net.state_dict().items()))}
+    g = torch.Generator().manual_seed(151)
+    for k, (n, h, w) in enumerate([(2, 64, 64), (1, 40, 56)]):
+        base = torch.rand(n, 3, h // 8 + 2, w // 8 + 2, generator=g)
+        img = F_interp(base, (h + 8, w + 8))
+        ref, supp = img[:, :, 4:-4, 4:-4].contiguous(), img[:, :, 2:-6, 5:-3].contiguous()      # the same scene shifted by (2, -1) px
+        ref = (ref + 0.05 * torch.rand(ref.shape, generator=g)).clamp(0, 1)
+        with torch.no_grad():
+            flow = net(ref, supp)
+        d[f"ref_{k}"], d[f"supp_{k}"], d[f"flow_{k}"] = _np(ref), _np(supp), _np(flow)
+        print(f"G15 pair set {k}: flow mean {flow.mean().item():.4f} abs max {flow.abs().max().item():.4f}")
+    np.savez_compressed(os.path.join(OUT, "g15_spynet.npz"), **d)
+
+
+def F_interp(t, size):
+    return torch.nn.functional.interpolate(t, size=size, mode="bicubic", align_corners=False)
+
+
 def _absent_third_party_stubs():
     """sys.modules stand-ins for THIRD-PARTY packages that are not installed here (skimage, mmedit, torchvision, h5py-free
     paths): they carry no arithmetic of the reference.  `torchvision.transforms.functional.to_tensor` is restated for the
@@ -548,7 +576,7 @@ def main():
     gens = {"g1": lambda: g1_model(BASIC_MODEL), "g2": lambda: g2_block(Block), "g3": lambda: g3_pretrained(BASIC_MODEL),
             "g4": g4_pixel_shuffle, "g5": lambda: g5_rounding(ops), "g6": lambda: g6_split_block(wdsr_b), "g7": g7_g8_vsr,
             "g10": g10_nas_model, "g11": g11_g12_video_models, "g13": lambda: g13_set5_shaped(BASIC_MODEL), "g9": g9_metrics,
-            "g14": g14_patches}
+            "g14": g14_patches, "g15": g15_spynet}
     only = [a for a in sys.argv[1:] if not a.startswith("-")]          # e.g. `make_golden.py g9 g14`: just those fixtures
     for name, fn in gens.items():
         if not only or name in only:
