@@ -8,11 +8,14 @@ A "step" is one pass of the hot path over one batch of synthetic 48x48 LR patche
 in HBM: forward (head, 16 fused residual blocks, fused tail+skip+PixelShuffle), L1 loss, backward,
 Adam step -- what pretrain.py's train() does per batch (reference pretrain.py:61-80).  Workload at
 every N: BASELINE.json configs[1] (x4, 16 blocks / 24 units, bf16 storage, batch 32 per GPU, weak
-scaling).  N = 1 times `model.train_step` (loss folded into the tail backward, Adam kernel, one C call);
-for N > 1 the model is wrapped in DistributedDataParallel over RCCL as pretrain.py:239 does and the step
-is forward / F.l1_loss / backward (bucketed all-reduce) / Adam.  The line also carries the same step through
-the plain nn.Module route (`unfused_ms_per_step`) and with the per-step `loss.item()` of pretrain.py:82
-(`ms_per_step_with_item_sync`), and the per-step distribution (median, p10, p90 from HIP events).
+scaling).  The timed step is `model.train_step` (loss folded into the tail backward, Adam kernel): one C call at
+N = 1; at N > 1 forward + backward, ONE RCCL all-reduce (average) of the 0.77 MB flat gradient on the compute stream,
+Adam kernel (`--overlap`: the all-reduce in two halves, the first under the early half of the backward; both are
+timed at N > 1 and the other one is printed as `alt_route_ms_per_step`, so the scaling run decides the default;
+`--ddp-wrapper`: torch's DistributedDataParallel as pretrain.py:239 wraps it).  The line also carries the reference's own
+loop on the drop-in route (`reference_surface_ms_per_step`: pretrain.py:69-82 with training.L1Loss / training.Adam and
+`loss.item()` every step), the plain nn.Module + torch loss + torch Adam route (`unfused_ms_per_step`), the fused step with
+the per-step `loss.item()` (`ms_per_step_with_item_sync`), and the per-step distribution (median, p10, p90, HIP events).
 
 Rank 0 prints ONE JSON line (metric, value, ..., roofline, cpu_baseline).
 """
@@ -91,10 +94,45 @@ def cpu_baseline(budget_s=20.0):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 30:
             break
-    return {"value": round(BATCH * HR_MPIX_PER_PATCH * n / el, 4), "unit": "HR-Mpix/s",
-            "cores": best_n, "kind": "port",
-            "sample": f"{n} full train steps (fwd+L1+bwd+Adam) of the same workload, batch {BATCH}, fp32, "
-                      f"{el:.1f} s on {best_n} threads (fastest of 8/16/32 threads on a {ncpu}-CPU host)"}
+    out = {"value": round(BATCH * HR_MPIX_PER_PATCH * n / el, 4), "unit": "HR-Mpix/s",
+           "cores": best_n, "kind": "port",
+           "sample": f"{n} full train steps (fwd+L1+bwd+Adam) of the same workload, batch {BATCH}, fp32, "
+                     f"{el:.1f} s on {best_n} threads (fastest of 8/16/32 threads on a {ncpu}-CPU host)"}
+    # BASELINE config 1 (the reference's own CPU-runnable case): x4, 4 blocks / 24 units, ONE 48x48 patch, fp32
+    ns1 = model_ns()
+    ns1.num_blocks = 4
+    torch.manual_seed(0)
+    m1 = OracleBasicModel(ns1).train()
+    opt1 = torch.optim.Adam(m1.parameters(), lr=1e-3)
+    x1, hr1 = torch.rand(1, 3, LR, LR), torch.rand(1, 3, LR * SCALE, LR * SCALE)
+
+    def step1():
+        opt1.zero_grad()
+        torch.nn.functional.l1_loss(m1(x1), hr1).backward()
+        opt1.step()
+
+    def rate(fn, budget):
+        fn()
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget and k < 400:
+            fn()
+            k += 1
+        return k, time.perf_counter() - t0
+    best1 = None
+    for nt in sorted({min(v, ncpu) for v in (1, 4, 8)}):      # a single patch does not feed many threads
+        torch.set_num_threads(nt)
+        k, el1 = rate(step1, 1.0)
+        if best1 is None or k / el1 > best1[0]:
+            best1 = (k / el1, nt)
+    torch.set_num_threads(best1[1])
+    k, el1 = rate(step1, 3.0)
+    m1.eval()
+    with torch.no_grad():
+        kf, elf = rate(lambda: m1(x1), 2.0)
+    out["c1"] = {"workload": "BASELINE config 1: x4, 4 blocks / 24 units, batch 1, 48x48, fp32", "cores": best1[1],
+                 "train_step_HR_Mpix_s": round(HR_MPIX_PER_PATCH * k / el1, 4), "forward_HR_Mpix_s": round(HR_MPIX_PER_PATCH * kf / elf, 4),
+                 "sample": f"{k} train steps in {el1:.1f} s, {kf} forwards in {elf:.1f} s"}
+    return out
 
 
 def main():
@@ -213,6 +251,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = float(loss.detach())
+    alt_ms = None
+    if use_ddp and fused and model.nb_split:
+        # the other data-parallel route (overlapped halves <-> one all-reduce), same steps: the scaling run decides the default
+        alt = not bool(args.overlap)
+
+        def step_alt():
+            return model.train_step(x, hr, state, process_group=pg, overlap=alt)
+        for _ in range(max(args.warmup // 2, 2)):
+            step_alt()
+        sync()
+        ta = time.perf_counter()
+        for _ in range(args.steps):
+            step_alt()
+        sync()
+        alt_el = time.perf_counter() - ta
+        if world > 1:
+            t = torch.tensor([alt_el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            alt_el = t.item()
+        alt_ms = alt_el / args.steps * 1e3
 
     # the same step, untimed for `value`: per-step distribution (HIP events on the launch stream, no host sync inside the
     # loop), with the per-step loss.item() sync of pretrain.py:82, and through the plain nn.Module / torch.optim route
@@ -397,6 +455,9 @@ def main():
             "per_step_ms": {"n": nd, "median": round(dist_ms[nd // 2], 4), "p10": round(dist_ms[nd // 10], 4),
                             "p90": round(dist_ms[(nd * 9) // 10], 4)},
             "ms_per_step_with_item_sync": round(item_ms, 4),
+            "alt_route_ms_per_step": None if alt_ms is None else round(alt_ms, 4),
+            "alt_route": None if alt_ms is None else ("one all-reduce after the backward" if args.overlap else
+                                                      "all-reduce in two halves, the first under the early half of the backward"),
             "unfused_ms_per_step": None if unfused_ms is None else round(unfused_ms, 4),
             "reference_surface_ms_per_step": None if ref_surface_ms is None else round(ref_surface_ms, 4),
             "reference_surface": "pretrain.py:69-82 verbatim (zero_grad / model(lr) / criterion / backward / optimizer.step / "

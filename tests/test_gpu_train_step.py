@@ -193,7 +193,7 @@ def test_drop_in_loss_other_uses_of_the_output_still_work():
     (torch.nn.functional.l1_loss(sr, hr) + 0.1 * sr.mean()).backward()
     ref = m.flat.grad
     assert float((g - ref).abs().max()) <= 5e-3 * float(ref.abs().max())        # (bf16: the two gradients are rounded separately)
-    assert float((g - ref).norm()) <= 2e-3 * float(ref.norm())
+    assert float((g - ref).norm()) <= 5e-3 * float(ref.norm())
     assert float(crit(sr.detach(), hr)) == pytest.approx(float(torch.nn.functional.l1_loss(sr.detach(), hr)), rel=1e-6)
     with torch.no_grad():
         m.eval()

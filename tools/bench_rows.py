@@ -85,6 +85,19 @@ with torch.no_grad():
     tf = timeit(lambda: propagate(clip, fl_f, fl_b, bt, ft, flow_warp), n=10, warm=3)
 out["C4_vsr_propagation_bf16"] = {"clips": b, "frames": n, "train_ms": round(t * 1e3, 3), "fwd_ms": round(tf * 1e3, 3),
                                   "LR_frames_per_s_fwd": round(b * n / tf, 1)}
+# SPyNet on C4's frame pairs: 8 clips x 4 pairs x 2 directions of 64 x 64 (7x7 conv pyramid as MFMA kernels)
+from mobilesuperresolution_amd.models import SpyNet, BasicVSR_origin
+sp = SpyNet().to(dev).eval()
+r1, r2 = torch.rand(64, 3, 64, 64, device=dev), torch.rand(64, 3, 64, 64, device=dev)
+tsp = timeit(lambda: sp(r1, r2), n=10, warm=3)
+# 2 x 49 x (8*32 + 32*64 + 64*32 + 32*16 + 16*2) flop per pixel and level
+gf = 64 * sum((64 >> l) ** 2 for l in range(6)) * 2 * 49 * (8 * 32 + 32 * 64 + 64 * 32 + 32 * 16 + 16 * 2) / 1e9
+out["spynet_64_pairs_64x64"] = {"ms": round(tsp * 1e3, 3), "GFLOP": round(gf, 1), "TFLOP_s": round(gf / tsp / 1e3, 1)}
+bvo = BasicVSR_origin(num_feat=24, num_block=8, hot_dtype="bf16").to(dev).eval()
+with torch.no_grad():
+    tb = timeit(lambda: bvo(clip, 256, 256), n=5, warm=2)
+out["BasicVSR_origin_fwd_with_spynet_8clips"] = {"ms": round(tb * 1e3, 3)}
+out["C2_bf16_batch256"] = sr_step(argparse.Namespace(**base, num_blocks=16, num_residual_units=24, hot_dtype="bf16"), 256)
 feat = torch.rand(32, 24, 64, 64, device=dev)
 flow = torch.rand(32, 64, 64, 2, device=dev) * 4 - 2
 with torch.no_grad():
