@@ -21,6 +21,15 @@
 
 extern "C" int sr_abi_version(void) { return 11; }
 
+// A/B switches between a kernel and the one it replaced are live in the diagnostic build only (build.py --debug); in the product
+// library they are the constant false, and the kernels only they reach are not instantiated.  (SR_NAS_FWD_SPLIT / SR_NAS_BWD_SPLIT
+// stay: the parity tests chain the fused NAS kernels to the separately tested ones through them.)
+#ifdef SR_DEBUG_STAMPS
+#define SR_AB(name) (getenv(name) != nullptr)
+#else
+#define SR_AB(name) false
+#endif
+
 namespace {
 
 template <typename T, int F, int E, int L>
@@ -229,7 +238,7 @@ int launch_wgrad_saved(const void* x, const void* dy, const void* tsave, const v
   typedef __bf16 T;
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
   dim3 grid(wgs, layers);
-  static const bool env_a15 = getenv("SR_WGRAD_A15") != nullptr;        // the 15-wave kernel, kept for A/B measurements
+  static const bool env_a15 = SR_AB("SR_WGRAD_A15");        // the 15-wave kernel, kept for A/B measurements
   const bool old_a = env_a15 || (long)N * tiles_x * tiles_y * C::TH * C::TW >= (1L << 31);   // (the 8-wave kernel indexes pixels in 32 bits)
   if constexpr (F == 24) {
     if (!old_a)
@@ -240,7 +249,7 @@ int launch_wgrad_saved(const void* x, const void* dy, const void* tsave, const v
     hipLaunchKernelGGL((wdsr_block_wgrad_saved_kernel<T, F, E, L, 0>), grid, dim3(64 * WgradSavedCfg<F, E, L, 0>::NWAVES), 0, st,
                        (const T*)x, (const T*)dtsave, (const T*)wblob, cinit, pa, N, H, W, tiles_x, tiles_x * tiles_y, x_ls,
                        side_ls, w_ls, c_ls);
-  static const bool old_b = getenv("SR_WGRAD_B9") != nullptr;           // the tap-per-wave kernel, kept for A/B measurements
+  static const bool old_b = SR_AB("SR_WGRAD_B9");           // the tap-per-wave kernel, kept for A/B measurements
   if (!old_b)
     hipLaunchKernelGGL((wdsr_wgrad_b8_kernel<F, E, L>), grid, dim3(WgradB8Cfg<F, E, L>::NTHREADS), 0, st, (const T*)dy, (const T*)tsave,
                        pb, N, H, W, tiles_x, tiles_x * tiles_y, dy_ls, side_ls);
@@ -649,7 +658,7 @@ extern "C" int sr_nas_dw_fwd(const void* yin, void* V, const float* dwp, int N, 
   if (!yin || !V || !dwp || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
   hipStream_t st = (hipStream_t)stream;
   const long vs = (long)N * H * W * F;
-  static const bool valu_dw = getenv("SR_NAS_DW_VALU") != nullptr;     // the VALU stencils also in bf16 mode (A/B measurements)
+  static const bool valu_dw = SR_AB("SR_NAS_DW_VALU");     // the VALU stencils also in bf16 mode (A/B measurements)
   if (dtype == SR_DTYPE_BF16 && !valu_dw && (F == 24 || F == 32)) {      // lane = channel, packed bf16 dot products (csrc/nas_dw_lc.h)
     typedef NasCfg<24> C;
     const int tx = (W + C::TW - 1) / C::TW;
@@ -696,7 +705,7 @@ extern "C" int sr_nas_dw_bwd(const void* yin, const void* GZ, const void* gy, vo
   if (!yin || !GZ || !gy || !gyin || !dwp || !partial || wgs <= 0 || N <= 0 || H <= 0 || W <= 0) return -2;
   hipStream_t st = (hipStream_t)stream;
   const long vs = (long)N * H * W * F;
-  static const bool valu_dw = getenv("SR_NAS_DW_VALU") != nullptr;
+  static const bool valu_dw = SR_AB("SR_NAS_DW_VALU");
   if (dtype == SR_DTYPE_BF16 && !valu_dw && (F == 24 || F == 32)) {      // lane = channel (csrc/nas_dw_lc.h); the dW part of the slab is sr_nas_dw_wgrad's
     typedef NasCfg<24> C;
     const int tx = (W + C::TW - 1) / C::TW, tpi = tx * ((H + C::TH - 1) / C::TH);
@@ -718,7 +727,7 @@ extern "C" int sr_nas_dw_wgrad(const void* yin, const void* GZ, const float* dwp
   if (!yin || !GZ || !dwp || !partial || wgs <= 0 || N <= 0 || H <= 0 || W <= 0) return -2;
   hipStream_t st = (hipStream_t)stream;
   const long vs = (long)N * H * W * F;
-  static const bool wgrad_split = getenv("SR_NAS_WGRAD_SPLIT") != nullptr;
+  static const bool wgrad_split = SR_AB("SR_NAS_WGRAD_SPLIT");
   if (dtype == SR_DTYPE_BF16 && !wgrad_split && (F == 24 || F == 32)) {   // the three stencils from one workgroup per tile
     typedef NasCfg<24> C;
     const int tx = (W + C::TW - 1) / C::TW, tpi = tx * ((H + C::TH - 1) / C::TH);
@@ -1051,7 +1060,7 @@ extern "C" int sr_nas_body_fwd(void* ys, void* V, const float* dwp, long dwp_bs,
   const size_t act = (size_t)N * H * W * F * (dtype == SR_DTYPE_BF16 ? 2 : 4);
   // bf16: depthwise + pointwise of a block from one launch (csrc/nas_dw_lc.h nas_block_fwd_kernel); SR_NAS_FWD_SPLIT=1 (read per
   // call, so a test can compare both routes in one process): the two kernels
-  const bool fused = dtype == SR_DTYPE_BF16 && (F == 24 || F == 32) && N <= 65535 && !getenv("SR_NAS_FWD_SPLIT") && !getenv("SR_NAS_DW_VALU");
+  const bool fused = dtype == SR_DTYPE_BF16 && (F == 24 || F == 32) && N <= 65535 && !getenv("SR_NAS_FWD_SPLIT") && !SR_AB("SR_NAS_DW_VALU");
   for (int i = 0; i < nb; ++i) {
     char* yi = (char*)ys + (size_t)i * act;
     char* Vi = (char*)V + (size_t)i * 3 * act;
@@ -1092,7 +1101,7 @@ extern "C" int sr_nas_body_bwd(const void* ys, const void* V, const void* g_out,
   const int tx_f = (W + NasCfg<24>::TW - 1) / NasCfg<24>::TW, tpi_f = tx_f * ((H + NasCfg<24>::TH - 1) / NasCfg<24>::TH);
   const long vs_f = (long)N * H * W * F;
   const bool fused = dtype == SR_DTYPE_BF16 && (F == 24 || F == 32) && (long)N * tpi_f <= wgs && !getenv("SR_NAS_BWD_SPLIT") &&
-                     !getenv("SR_NAS_WGRAD_SPLIT") && !getenv("SR_NAS_DW_VALU");
+                     !SR_AB("SR_NAS_WGRAD_SPLIT") && !SR_AB("SR_NAS_DW_VALU");
   for (int i = nb - 1; i >= 0; --i) {
     void* gin = (i & 1) ? g_tmp1 : g_tmp0;
     const char* yi = (const char*)ys + (size_t)i * act;
@@ -1209,7 +1218,7 @@ extern "C" int sr_wdsr_net_train_step(const sr_wdsr_net_t* n, float* m, float* v
   if ((rc = sr_wdsr_net_forward(n, SR_NET_SAVE_ACTS, stream))) return rc;
   // every parameter belongs to exactly one row of the weight-norm tables (the caller checks it: n_params == rows' elements),
   // so the Adam update rides on the weight-norm backward; SR_TRAIN_SEPARATE_ADAM=1: the two launches
-  static const bool separate = getenv("SR_TRAIN_SEPARATE_ADAM") != nullptr;
+  static const bool separate = SR_AB("SR_TRAIN_SEPARATE_ADAM");
   if (!separate && n->adam_in_wn_bwd) {
     const FusedAdam fa{m, v, AdamArgs{a->w_lerp, a->beta2, a->one_minus_beta2, a->bc2_sqrt, a->eps, a->neg_step_size}, n->loss_part,
                        n->wgs_tail, loss_scale, loss_out};
