@@ -5,6 +5,7 @@
 #include "wdsr_block.h"
 #include "wdsr_fwd_rs.h"
 #include "wdsr_fwd_stream.h"
+#include "wdsr_bwd_rs.h"
 #include "wdsr_wgrad_rs.h"
 #include "wdsr_ends.h"
 #include "wdsr_prep.h"
@@ -205,6 +206,13 @@ extern "C" int sr_wdsr_block2_bwd_data(const void* xa, const void* xb, const voi
   if (F != 24 || dtype != SR_DTYPE_BF16) return -1;
   typedef BlockCfg<24, 144, 20> C;
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
+  if (!SR_AB("SR_BWD2_OLD")) {                         // round 3: 8 waves, register-resident weights (csrc/wdsr_bwd_rs.h)
+    hipLaunchKernelGGL((wdsr_bwd_rs_kernel<24, 144, 20>), dim3(tiles_x * tiles_y, N), dim3(512), 0, (hipStream_t)stream, (const __bf16*)xa,
+                       (const __bf16*)xb, (const __bf16*)dyb, (__bf16*)dxb, (__bf16*)dxa, (const __bf16*)wa, (const __bf16*)wb, (__bf16*)dta,
+                       (__bf16*)dtb, H, W, tiles_x);
+    SR_HIP_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL((wdsr_block2_bwd_data_kernel<__bf16, 24, 144, 20>), dim3(tiles_x * tiles_y, N),
                      dim3(64 * C::NPT_H), 0, (hipStream_t)stream, (const __bf16*)xa, (const __bf16*)xb,
                      (const __bf16*)dyb, (__bf16*)dxb, (__bf16*)dxa, (const __bf16*)wa, (const __bf16*)wb, cia, cib,

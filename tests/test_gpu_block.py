@@ -283,8 +283,10 @@ def test_role_specialised_forward_matches_round1_kernels_and_itself(shape, f, nb
 
 
 @pytest.mark.parametrize("shape", [(3, 48, 48), (2, 20, 28), (1, 7, 9)])
-def test_block_pair_bwd_data_bit_identical_to_two_launches(shape):
-    """sr_wdsr_block2_bwd_data == two sr_wdsr_block_bwd_data launches, bit for bit (incl. ragged tiles)"""
+def test_block_pair_bwd_data_matches_two_launches_and_torch(shape):
+    """sr_wdsr_block2_bwd_data (round 3: csrc/wdsr_bwd_rs.h, register-resident weights, the skip term as the accumulator's initial
+    value) against two sr_wdsr_block_bwd_data launches of the round-1 kernel (G2-checked; same products, another summation
+    order), incl. ragged tiles; the saved dt images against torch's conv_transpose2d of the bf16 gradients"""
     from mobilesuperresolution_amd import _lib as L, hotpath as HP
     n, h, w = shape
     f = 24
@@ -299,11 +301,34 @@ def test_block_pair_bwd_data_bit_identical_to_two_launches(shape):
     HP.block_bwd_data(xb, dyb, d1, blob[1], cinit[1])
     HP.block_bwd_data(xa, d1, d0, blob[0], cinit[0])
     p1, p0 = torch.full_like(xa, float("nan")), torch.full_like(xa, float("nan"))
+    tiles = ((h + 11) // 12) * ((w + 23) // 24)
+    dts = torch.full((2, n, tiles, 288, 24), float("nan"), device="cuda", dtype=torch.bfloat16)
     L.check(L.lib().sr_wdsr_block2_bwd_data(xa.data_ptr(), xb.data_ptr(), dyb.data_ptr(), p1.data_ptr(), p0.data_ptr(),
                                             blob[0].data_ptr(), blob[1].data_ptr(), cinit[0].data_ptr(), cinit[1].data_ptr(),
-                                            None, None, n, h, w, f, 1, L.stream_ptr()), "pair bwd")
+                                            dts[0].data_ptr(), dts[1].data_ptr(), n, h, w, f, 1, L.stream_ptr()), "pair bwd")
+    q1, q0 = torch.full_like(xa, float("nan")), torch.full_like(xa, float("nan"))
+    L.check(L.lib().sr_wdsr_block2_bwd_data(xa.data_ptr(), xb.data_ptr(), dyb.data_ptr(), q1.data_ptr(), q0.data_ptr(),
+                                            blob[0].data_ptr(), blob[1].data_ptr(), cinit[0].data_ptr(), cinit[1].data_ptr(),
+                                            None, None, n, h, w, f, 1, L.stream_ptr()), "pair bwd, no dt")
     torch.cuda.synchronize()
-    assert torch.equal(p1, d1) and torch.equal(p0, d0)
+    assert torch.equal(p1, q1) and torch.equal(p0, q0)                 # (with and without the saved images)
+    _assert_same_up_to_summation_order(p1, d1, "dx of block b")
+    _assert_same_up_to_summation_order(p0, d0, "dx of block a")
+    # the saved dt images: dt = conv_transpose(dy, W3) on bf16 operands, tile-local [tile 12 x 24][288][24] with zeros in channels 20..23
+    # and outside the image
+    import torch.nn.functional as Fn
+    off = P.BlockGeom(24, 144, 20).off
+    for blk, dy in ((1, dyb), (0, p1)):
+        w3 = src[blk, off["w3"]:off["w3"] + 24 * 20 * 9].view(24, 20, 3, 3).bfloat16().float()
+        ref = Fn.conv_transpose2d(dy.float().permute(0, 3, 1, 2), w3, padding=1)          # (n, 20, h, w)
+        got = dts[blk].float()
+        th, tw = (h + 11) // 12, (w + 23) // 24
+        full = torch.zeros(n, th * 12, tw * 24, 24, device="cuda")
+        full[:, :h, :w, :20] = ref.permute(0, 2, 3, 1)
+        exp = full.view(n, th, 12, tw, 24, 24).permute(0, 1, 3, 2, 4, 5).reshape(n, tiles, 288, 24)
+        assert torch.isfinite(got).all()
+        err = float((got - exp).abs().max()) / float(exp.abs().max())
+        assert err <= 1e-2, (blk, err)
 
 
 @pytest.mark.parametrize("f,r,shape", [(24, 4, (3, 48, 48)), (24, 2, (2, 20, 28)), (32, 3, (1, 7, 9)), (32, 4, (2, 13, 50))])
