@@ -261,6 +261,8 @@ __global__ __launch_bounds__(512) void wdsr_bwd_rs_kernel(const __bf16* __restri
   const size_t tile_g = (size_t)n * gridDim.x + tile;
   const char* zeros = reinterpret_cast<const char*>(g_sr_const_chunks) + 16;
   const int lq = lane / C::FC, lc = lane - lq * C::FC;  // this lane's fixed place in every activation piece
+  SR_STAMP_DECL;
+  SR_STAMP();
 
   // a region of an image (zero outside it) by LDS-DMA: 21 pixels x 3 chunks (+ 1 chunk of the next pixel) per piece
   auto stage_region = [&](__bf16* dst, const __bf16* src, int y0, int x0, int rw, int npx, int p0) {
@@ -275,14 +277,34 @@ __global__ __launch_bounds__(512) void wdsr_bwd_rs_kernel(const __bf16* __restri
       dma_piece16(s, lds_addr(dst) + p * (R::PXP * C::FC * 16));
     }
   };
-  auto stage_w = [&](const __bf16* wsrc, int p0) {
+  auto stage_w = [&](const __bf16* wsrc, int lo, int hi, int p0) {     // staged fragments [lo, hi)
 #pragma unroll 1
-    for (int fr = (wave - p0) & 7; fr < R::NFR; fr += 8)
+    for (int fr = lo + ((wave - p0 - lo) & 7); fr < hi; fr += 8)
       dma_piece16(reinterpret_cast<const char*>(wsrc + (size_t)R::src_frag(fr) * 512 + lane * 8), lds_addr(WL) + fr * 1024);
   };
-  stage_w(wb, 0);
-  stage_region(DY, dyb, ty0 - 2, tx0 - 2, R::rw(0), R::np(0), 3);
-  stage_region(XB, xb, ty0 - 1, tx0 - 1, R::rw(1), R::np(1), 6);
+  // what P1b needs first -- the 3x3^T fragments and dy_b -- then what only P2b needs: x_b and the other 29 fragments, which land
+  // underneath P1b.  The second set is exactly SET2 / 8 pieces per wave, so a counted wait retires the first set only.
+  constexpr int SET2_REAL = R::pieces(R::np(1)) + R::NF1 + R::NF2T + R::NF1T;
+  constexpr int SET2 = (SET2_REAL + 7) / 8 * 8;        // (padded with repeats of one fragment: the same bytes to the same place)
+  stage_w(wb, R::L_W3T, R::L_W3T + R::NF3, 0);
+  stage_region(DY, dyb, ty0 - 2, tx0 - 2, R::rw(0), R::np(0), 6);
+  {                                                    // set 2 as ONE piece list: x_b's pieces, then W1, then W2T | W1T
+    constexpr int NPX1 = R::pieces(R::np(1));
+#pragma unroll 1
+    for (int p = wave; p < SET2; p += 8) {
+      if (p < NPX1) {
+        const int px_ = p * R::PXP + lq;
+        const int py = px_ / R::rw(1), pxx = px_ - py * R::rw(1);
+        const int Y = ty0 - 1 + py, X = tx0 - 1 + pxx;
+        const char* sp = zeros;
+        if (px_ < R::np(1) && Y >= 0 && Y < H && X >= 0 && X < W) sp = reinterpret_cast<const char*>(xb + img + ((size_t)Y * W + X) * C::F + lc * 8);
+        dma_piece16(sp, lds_addr(XB) + p * (R::PXP * C::FC * 16));
+      } else {
+        const int k0 = p - NPX1, k = k0 < R::NF1 + R::NF2T + R::NF1T ? k0 : 0, fr = k < R::NF1 ? k : R::L_W2T + (k - R::NF1);
+        dma_piece16(reinterpret_cast<const char*>(wb + (size_t)R::src_frag(fr) * 512 + lane * 8), lds_addr(WL) + fr * 1024);
+      }
+    }
+  }
   if (tid < 8) ONES[tid] = tid == 0 ? (__bf16)1.f : (__bf16)0.f;
   // rows of the dx image past region 1 (read by the padded taps of P1a, written by no tile)
   for (int i = tid; i < (R::npad(1) + 2 - R::np(1)) * R::KXL / 8; i += R::NTHREADS) {
@@ -291,8 +313,10 @@ __global__ __launch_bounds__(512) void wdsr_bwd_rs_kernel(const __bf16* __restri
     for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.f;
     *reinterpret_cast<bf16x8*>(DX + R::np(1) * R::KXL + i * 8) = z;
   }
-  wait_vmcnt<0>();
+  SR_STAMP();
+  wait_vmcnt<SET2 / 8>();                              // set 1 landed (this wave's pieces; the barrier joins the waves)
   __syncthreads();
+  SR_STAMP();
 
   BwP1<R> w1;
   BwP2<R> w2;
@@ -305,21 +329,32 @@ __global__ __launch_bounds__(512) void wdsr_bwd_rs_kernel(const __bf16* __restri
   __bf16* const dtb_tile = dtb ? dtb + tile_g * (C::TH * C::TW) * C::LP : nullptr;
   __bf16* const dta_tile = dta ? dta + tile_g * (C::TH * C::TW) * C::LP : nullptr;
   // ---- block b ----
-  bw_phase_dt<R, R::rw(1), R::np(1), 1>(DY, DT, w1, dtb_tile, H, W, ty0, tx0, wave, lane, pf2);
-  __syncthreads();                                     // dt_b complete; block b's weights are all in registers; dy_b's window reads are over
-  stage_w(wa, 0);                                      // block a's weights and x_a land underneath P2b
-  // (P2b still reads dy_b's centre pixels from DY: x_a goes there only after P2b -- see below)
+  bw_phase_dt<R, R::rw(1), R::np(1), 1>(DY, DT, w1, dtb_tile, H, W, ty0, tx0, wave, lane, [](int, int) {});
+  SR_STAMP();
+  wait_vmcnt<3>();                                     // set 2 (issued before this wave's >= 3 stores of the saved dt image ... or none)
+  if (!dtb_tile) wait_vmcnt<0>();
+  __syncthreads();                                     // dt_b complete; x_b and block b's other weights landed; dy_b's window reads are over
+  w2.load(WL, lane);
+  __syncthreads();                                     // every wave holds block b's weights: their LDS copy is free
+  stage_w(wa, 0, R::NFR, 0);                           // block a's weights land underneath P2b
+  SR_STAMP();
+  // (P2b still reads dy_b's centre pixels from DY: x_a goes there only after P2b)
   bw_phase_dx<R, R::rw(1), R::np(1), 1>(XB, ONES, DT, DY, DX, dxb + img, w2, H, W, ty0, tx0, wave, lane);
+  SR_STAMP();
   static_assert((R::np(1) + 31) / 32 >= R::NW, "every wave stores at least one tile of dx_b after its weight pieces");
   wait_vmcnt<3>();                                     // this wave's weight pieces (issued before its >= 3 dx stores) have landed
   __syncthreads();                                     // dx_b (= dy_a) complete in LDS; block a's weights landed; DY is free
+  SR_STAMP();
   stage_region(DY, xa, ty0, tx0, R::rw(2), R::np(2), 0);
   // ---- block a ----
   w1.load(WL, lane);
   bw_phase_dt<R, R::rw(2), R::np(2), 0>(DX, DT, w1, dta_tile, H, W, ty0, tx0, wave, lane, pf2);
+  SR_STAMP();
   static_assert((R::np(2) + 31) / 32 >= R::NW, "every wave has a tile of dt_a");
   if (dta_tile) wait_vmcnt<3>();                       // x_a's pieces, issued before this wave's >= 3 stores of the saved dt image
   else wait_vmcnt<0>();
   __syncthreads();                                     // dt_a complete, x_a landed
+  SR_STAMP();
   bw_phase_dx<R, R::rw(2), R::np(2), 0>(DY, ONES, DT, DX, nullptr, dxa + img, w2, H, W, ty0, tx0, wave, lane);
+  SR_STAMP();
 }

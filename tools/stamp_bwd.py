@@ -1,4 +1,4 @@
-"""Diagnostic: per-phase, per-wave timeline of wdsr_block2_bwd_data_kernel from in-kernel stamps (C2 shape: batch 32, 48x48, 24 units).
+"""Diagnostic: per-phase, per-wave timeline of wdsr_bwd_rs_kernel (sr_wdsr_block2_bwd_data) from in-kernel stamps (C2 shape: batch 32, 48x48, 24 units).
 Needs the diagnostic library: python -m mobilesuperresolution_amd.build --debug.
     python tools/stamp_bwd.py [batch]"""
 import os, sys
@@ -40,7 +40,7 @@ s = raw[..., 0] * 10.0
 nst = int((s[0, 0] > 0).sum()); nw = int((s[0, :, 0] > 0).sum())
 t0 = s[:, :nw, 0].min()
 print(f"{tiles} workgroups, {nw} waves, {nst} stamps; first start -> last end {s[:, :nw, nst - 1].max() - t0:.0f} ns; start spread {s[:, 0, 0].max() - t0:.0f} ns")
-names = ["issue staging (DMA weights, region loads + stores)", "barrier", "phase 1 (dxB, 12 tiles)", "barrier + xA store + barrier", "phase 2 (dxA, 9 tiles)"]
+names = ["issue staging (set 1 + set 2)", "wait set 1 + barrier", "P1b dt_b (12 tiles)", "wait set 2 + barrier + load w2 + barrier + issue Wa", "P2b dx_b (12 tiles)", "wait Wa + barrier", "issue x_a + load w1 + P1a dt_a (9 tiles)", "wait x_a + barrier", "P2a dx_a (9 tiles)"]
 for k in range(nst - 1):
     d = s[:, :nw, k + 1] - s[:, :nw, k]
     print("%-52s median %6.0f ns  p10 %6.0f  p90 %6.0f   per-wave median: %s" % (names[k] if k < len(names) else k, np.median(d),
