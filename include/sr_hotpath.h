@@ -180,16 +180,22 @@ typedef struct sr_c3_unpack {
  * Input: EITHER x0 [N,H,W,ci0] (ci0 = 32: the 27-channel concat zero-padded, or 24) OR warp (frame, state, flow; ci0 = 32)
  * -- exactly one of the two is non-NULL.  acts [(nb+1)][N,H,W,24] receives a_0..a_nb (a_nb = output), mids [nb][N,H,W,24]
  * the post-ReLU conv1 outputs; blob = every conv's packed weights in one buffer, conv k (0 = first conv, 1+2i / 2+2i =
- * conv1 / conv2 of block i) at ELEMENT offset blob_off[k] (host array). */
+ * conv1 / conv2 of block i) at ELEMENT offset blob_off[k] (host array).
+ * TWO TRUNKS IN ONE CALL (n_dir > 0; the two time directions of a BasicVSR frame step, basicvsr_arch.py:67-88, are independent):
+ * images [0, n_dir) of the batch run through the trunk whose packed weights sit at `blob`, images [n_dir, N) through the one
+ * `blob_dir_stride` ELEMENTS behind it (same layout, same blob_off); n_dir = 0: one trunk. */
 int sr_c3_trunk_fwd(const void* x0, const sr_c3_warp_t* warp, void* acts, void* mids, const void* blob,
-                    const long* blob_off, int nb, int N, int H, int W, int ci0, int dtype, sr_stream_t stream);
+                    const long* blob_off, int nb, int N, int H, int W, int ci0, int dtype, int n_dir, long blob_dir_stride,
+                    sr_stream_t stream);
 /* Its backward.  ga [(nb+1)][N,H,W,24]: the caller writes d(loss)/d(a_nb) into slot nb, the call fills the other
  * slots; gt [nb][...] scratch (gradients at the post-ReLU points); parts [(1+2nb)][wgs][9*1024] fp32 weight-gradient
  * slabs per conv (layout packing.c3_tables "grad"); dx0 (may be NULL unless warp->dstate / dflow is asked for) =
- * gradient w.r.t. the first conv's 32-channel input. */
+ * gradient w.r.t. the first conv's 32-channel input.
+ * n_dir > 0 (two trunks, as in sr_c3_trunk_fwd): wgs must be even -- the first wgs / 2 slabs of every conv sum over the first trunk's
+ * images, the others over the second's -- and unpack->gflat receives the two trunks' gradients one behind the other. */
 int sr_c3_trunk_bwd(const void* x0, const sr_c3_warp_t* warp, const void* acts, const void* mids, void* ga, void* gt,
                     const void* blob, const long* blob_off, float* parts, void* dx0, const sr_c3_unpack_t* unpack, int nb,
-                    int wgs, int N, int H, int W, int ci0, int dtype, sr_stream_t stream);
+                    int wgs, int N, int H, int W, int ci0, int dtype, int n_dir, long blob_dir_stride, sr_stream_t stream);
 
 /* Training patches cut on device from a resident uint8 cache.  Replaces, per patch,
  * ImageSuperResolutionDataset._sample_patch + _augment + to_tensor, datasets/_isr.py:68-121.  cache: every LR and HR image

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SR_HOTPATH_LIB_PATH (tools/ only): an explicitly named build of the same sources (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("SR_HOTPATH_LIB_PATH") or os.path.join(
     _HERE, "libsr_hotpath_dbg.so" if os.environ.get("SR_HOTPATH_DEBUG_LIB") == "1" else "libsr_hotpath.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
 
 _P, _I, _Z, _L, _F = c_void_p, c_int, c_size_t, ctypes.c_long, ctypes.c_float
@@ -31,8 +31,8 @@ SIGNATURES = {
     "sr_probe_launch_floor": ([_P, _I, _I, _I, _I, _I, _P], _I),
     "sr_probe_launch_floor_graph": ([_P, _I, _I, _I, _I, _I, _I, _P, _P], _I),
     "sr_debug_set_stamps": ([_P, _L], _I),
-    "sr_c3_trunk_fwd": ([_P] * 6 + [_I] * 6 + [_P], _I),
-    "sr_c3_trunk_bwd": ([_P] * 11 + [_I] * 7 + [_P], _I),
+    "sr_c3_trunk_fwd": ([_P] * 6 + [_I] * 7 + [_L, _P], _I),
+    "sr_c3_trunk_bwd": ([_P] * 11 + [_I] * 8 + [_L, _P], _I),
     "sr_tail_bwd": ([_P, _P, _P, _F, _P, _P, _P] + [_I] * 7 + [_P], _I),
     "sr_nas_dw_wgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "sr_wdsr_block_fwd_repeat": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),

@@ -21,6 +21,12 @@ struct C3Cfg {
   static constexpr int DZ_ELEMS = (NPXH_PAD + 2) * CO;          // masked output-gradient tile with halo
 };
 
+// Two trunks in ONE launch (the two time directions of a BasicVSR frame step are independent): images [0, n_dir) of the batch use the
+// weights at the blob pointer, images [n_dir, ..) those `w_ds` elements behind it (the other trunk's blob, same layout); n_dir = 0: one
+// trunk.  The weight-gradient launches split their workgroups the same way (first half of the grid: first trunk's images).
+struct C3Dir { long w_ds; int n_dir; };
+SR_DEV long c3_dir_off(const C3Dir& d, int n) { return (d.n_dir > 0 && n >= d.n_dir) ? d.w_ds : 0; }
+
 template <int ACT> SR_DEV float c3_act(float v) {
   if (ACT == 1) return fmaxf(v, 0.f);
   if (ACT == 2) return v > 0.f ? v : 0.1f * v;
@@ -187,9 +193,10 @@ SR_DEV void c3_stage_dz(T* DZ, const T* __restrict__ dA, const T* __restrict__ A
 // ---------------------------------------------------------------------------------------------
 template <typename T, int CI, int ONES, int ACT, bool ADD, bool WARP = false>
 __global__ __launch_bounds__((64 * C3Cfg::NPT_O)) void c3_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
-                                                                     T* __restrict__ y, const T* __restrict__ wblob,
-                                                                     int H, int W, int tiles_x, C3WarpSrc<T> warp) {
+                                                                     T* __restrict__ y, const T* __restrict__ wblob_,
+                                                                     int H, int W, int tiles_x, C3WarpSrc<T> warp, C3Dir dir) {
   static_assert(!WARP || (CI == 32 && ONES == 27), "the gathered input is the 27-channel concat");
+  const T* const wblob = wblob_ + c3_dir_off(dir, blockIdx.y);
   typedef C3Cfg C;
   typedef typename FragOf<T>::half_type HalfT;
   constexpr int NTHREADS = 64 * C::NPT_O;
@@ -257,8 +264,9 @@ __global__ __launch_bounds__((64 * C3Cfg::NPT_O)) void c3_fwd_kernel(const T* __
 template <typename T, int CI, int ACT, bool ADD>
 __global__ __launch_bounds__((64 * C3Cfg::NPT_O)) void c3_bwd_data_kernel(const T* __restrict__ dA, const T* __restrict__ A,
                                                                           const T* __restrict__ add, T* __restrict__ dx,
-                                                                          const T* __restrict__ wblob, int H, int W,
-                                                                          int tiles_x) {
+                                                                          const T* __restrict__ wblob_, int H, int W,
+                                                                          int tiles_x, C3Dir dir) {
+  const T* const wblob = wblob_ + c3_dir_off(dir, blockIdx.y);
   typedef C3Cfg C;
   typedef typename FragOf<T>::half_type HalfT;
   constexpr int NTHREADS = 64 * C::NPT_O;
@@ -317,7 +325,7 @@ template <typename T, int CI, int ONES, int ACT, bool WARP = false>
 __global__ __launch_bounds__((64 * 9)) void c3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dA,
                                                             const T* __restrict__ A, float* __restrict__ partial, int N,
                                                             int H, int W, int tiles_x, int tiles_per_img, long x_ls,
-                                                            long d_ls, long a_ls, long p_ls, C3WarpSrc<T> warp) {
+                                                            long d_ls, long a_ls, long p_ls, C3WarpSrc<T> warp, int n_dir) {
   typedef C3Cfg C;
   constexpr int NTHREADS = 576;
   // blockIdx.y = layer: several convolutions of the same kind in one launch (element strides between layers)
@@ -331,7 +339,12 @@ __global__ __launch_bounds__((64 * 9)) void c3_wgrad_kernel(const T* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int uy = wave / 3, ux = wave - uy * 3;
   f32x16 acc = zero16();
-  for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
+  // n_dir > 0 (two trunks in one launch): the first half of the workgroups sums over images [0, n_dir), the second half over the rest
+  const int half = gridDim.x / 2, second = (n_dir > 0 && (int)blockIdx.x >= half) ? 1 : 0;
+  const int t_begin = n_dir > 0 ? second * n_dir * tiles_per_img + ((int)blockIdx.x - second * half) : (int)blockIdx.x;
+  const int t_end = n_dir > 0 ? (second ? N : n_dir) * tiles_per_img : N * tiles_per_img;
+  const int t_step = n_dir > 0 ? half : (int)gridDim.x;
+  for (int t = t_begin; t < t_end; t += t_step) {
     const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
     const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
     __syncthreads();
@@ -374,9 +387,11 @@ struct C3Pair {
 
 template <typename T>
 __global__ __launch_bounds__((64 * C3Pair::NPT_H)) void c3_resblock_fwd_kernel(const T* __restrict__ x, T* __restrict__ tmid,
-                                                                               T* __restrict__ y, const T* __restrict__ w1,
-                                                                               const T* __restrict__ w2, int H, int W,
-                                                                               int tiles_x) {
+                                                                               T* __restrict__ y, const T* __restrict__ w1_,
+                                                                               const T* __restrict__ w2_, int H, int W,
+                                                                               int tiles_x, C3Dir dir) {
+  const T* const w1 = w1_ + c3_dir_off(dir, blockIdx.y);
+  const T* const w2 = w2_ + c3_dir_off(dir, blockIdx.y);
   typedef C3Cfg C;
   typedef C3Pair P;
   typedef typename FragOf<T>::type FragT;
@@ -489,8 +504,10 @@ __global__ __launch_bounds__((64 * C3Pair::NPT_H)) void c3_resblock_fwd_kernel(c
 // c3_bwd_data<none> followed by c3_bwd_data<ReLU, +add>.
 template <typename T>
 __global__ __launch_bounds__((64 * C3Pair::NPT_H)) void c3_resblock_bwd_data_kernel(
-    const T* __restrict__ g, const T* __restrict__ tmid, T* __restrict__ gt, T* __restrict__ ga, const T* __restrict__ w1,
-    const T* __restrict__ w2, int H, int W, int tiles_x) {
+    const T* __restrict__ g, const T* __restrict__ tmid, T* __restrict__ gt, T* __restrict__ ga, const T* __restrict__ w1_,
+    const T* __restrict__ w2_, int H, int W, int tiles_x, C3Dir dir) {
+  const T* const w1 = w1_ + c3_dir_off(dir, blockIdx.y);
+  const T* const w2 = w2_ + c3_dir_off(dir, blockIdx.y);
   typedef C3Cfg C;
   typedef C3Pair P;
   typedef typename FragOf<T>::type FragT;

@@ -20,7 +20,7 @@
 #include "train_step.h"
 #include "pixel_shuffle.h"
 
-extern "C" int sr_abi_version(void) { return 11; }
+extern "C" int sr_abi_version(void) { return 12; }
 
 // A/B switches between a kernel and the one it replaced are live in the diagnostic build only (build.py --debug); in the product
 // library they are the constant false, and the kernels only they reach are not instantiated.  (SR_NAS_FWD_SPLIT / SR_NAS_BWD_SPLIT
@@ -459,15 +459,15 @@ template <typename T> C3WarpSrc<T> c3_warp_src(const sr_c3_warp_t* w) {
 }
 template <typename T>
 int c3_fwd_t(const void* x, const void* res, void* y, const void* w, int N, int H, int W, int CI, int act, hipStream_t st,
-             const sr_c3_warp_t* warp = nullptr) {
+             const sr_c3_warp_t* warp = nullptr, C3Dir dir = C3Dir{0, 0}) {
   const C3Grid g = c3_grid(N, H, W);
   const dim3 blk(64 * C3Cfg::NPT_O);
   const C3WarpSrc<T> ws = c3_warp_src<T>(warp);
-#define L(CI_, ONES_, ACT_, ADD_) hipLaunchKernelGGL((c3_fwd_kernel<T, CI_, ONES_, ACT_, ADD_>), g.grid, blk, 0, st, (const T*)x, (const T*)res, (T*)y, (const T*)w, H, W, g.tx, ws)
+#define L(CI_, ONES_, ACT_, ADD_) hipLaunchKernelGGL((c3_fwd_kernel<T, CI_, ONES_, ACT_, ADD_>), g.grid, blk, 0, st, (const T*)x, (const T*)res, (T*)y, (const T*)w, H, W, g.tx, ws, dir)
   if (warp) {
     if (CI != 32 || act != 2 || res) return -1;
     hipLaunchKernelGGL((c3_fwd_kernel<T, 32, 27, 2, false, true>), g.grid, blk, 0, st, (const T*)nullptr, (const T*)nullptr, (T*)y,
-                       (const T*)w, H, W, g.tx, ws);
+                       (const T*)w, H, W, g.tx, ws, dir);
   } else if (CI == 32 && act == 2 && !res) L(32, 27, 2, false);
   else if (CI == 24 && act == 1 && !res) L(24, 24, 1, false);
   else if (CI == 24 && act == 0 && res) L(24, 24, 0, true);
@@ -479,10 +479,10 @@ int c3_fwd_t(const void* x, const void* res, void* y, const void* w, int N, int 
 }
 template <typename T>
 int c3_bwd_t(const void* dA, const void* A, const void* add, void* dx, const void* w, int N, int H, int W, int CI, int act,
-             hipStream_t st) {
+             hipStream_t st, C3Dir dir = C3Dir{0, 0}) {
   const C3Grid g = c3_grid(N, H, W);
   const dim3 blk(64 * C3Cfg::NPT_O);
-#define L(CI_, ACT_, ADD_) hipLaunchKernelGGL((c3_bwd_data_kernel<T, CI_, ACT_, ADD_>), g.grid, blk, 0, st, (const T*)dA, (const T*)A, (const T*)add, (T*)dx, (const T*)w, H, W, g.tx)
+#define L(CI_, ACT_, ADD_) hipLaunchKernelGGL((c3_bwd_data_kernel<T, CI_, ACT_, ADD_>), g.grid, blk, 0, st, (const T*)dA, (const T*)A, (const T*)add, (T*)dx, (const T*)w, H, W, g.tx, dir)
   if (CI == 32 && act == 2 && !add) L(32, 2, false);
   else if (CI == 24 && act == 1 && add) L(24, 1, true);
   else if (CI == 24 && act == 1 && !add) L(24, 1, false);
@@ -495,14 +495,14 @@ int c3_bwd_t(const void* dA, const void* A, const void* add, void* dx, const voi
 template <typename T>
 int c3_wgrad_t(const void* x, const void* dA, const void* A, float* partial, int wgs, int N, int H, int W, int CI, int act,
                hipStream_t st, int layers = 1, long x_ls = 0, long d_ls = 0, long a_ls = 0, long p_ls = 0,
-               const sr_c3_warp_t* warp = nullptr) {
+               const sr_c3_warp_t* warp = nullptr, int n_dir = 0) {
   const C3Grid g = c3_grid(N, H, W);
   const C3WarpSrc<T> ws = c3_warp_src<T>(warp);
-#define L(CI_, ONES_, ACT_) hipLaunchKernelGGL((c3_wgrad_kernel<T, CI_, ONES_, ACT_>), dim3(wgs, layers), dim3(576), 0, st, (const T*)x, (const T*)dA, (const T*)A, partial, N, H, W, g.tx, g.tpi, x_ls, d_ls, a_ls, p_ls, ws)
+#define L(CI_, ONES_, ACT_) hipLaunchKernelGGL((c3_wgrad_kernel<T, CI_, ONES_, ACT_>), dim3(wgs, layers), dim3(576), 0, st, (const T*)x, (const T*)dA, (const T*)A, partial, N, H, W, g.tx, g.tpi, x_ls, d_ls, a_ls, p_ls, ws, n_dir)
   if (warp) {
     if (CI != 32 || act != 2 || layers != 1) return -1;
     hipLaunchKernelGGL((c3_wgrad_kernel<T, 32, 27, 2, true>), dim3(wgs, 1), dim3(576), 0, st, (const T*)nullptr, (const T*)dA,
-                       (const T*)A, partial, N, H, W, g.tx, g.tpi, x_ls, d_ls, a_ls, p_ls, ws);
+                       (const T*)A, partial, N, H, W, g.tx, g.tpi, x_ls, d_ls, a_ls, p_ls, ws, n_dir);
   } else if (CI == 32 && act == 2) L(32, 27, 2);
   else if (CI == 24 && act == 1) L(24, 24, 1);
   else if (CI == 24 && act == 0) L(24, 24, 0);
@@ -537,21 +537,21 @@ extern "C" int sr_c3_wgrad(const void* x, const void* dA, const void* A, float* 
 // whole propagation trunk (ConvResidualBlocks.forward, models/basicvsr_arch.py:108-147) from one call
 template <typename T>
 static int c3_trunk_fwd_t(const void* x0, const sr_c3_warp_t* warp, void* acts_, void* mids_, const void* blob_,
-                          const long* boff, int nb, int N, int H, int W, int ci0, hipStream_t st) {
+                          const long* boff, int nb, int N, int H, int W, int ci0, hipStream_t st, C3Dir dir) {
   const size_t act = (size_t)N * H * W * 24;
   T* acts = (T*)acts_; T* mids = (T*)mids_; const T* blob = (const T*)blob_;
   int rc;
-  if ((rc = c3_fwd_t<T>(x0, nullptr, acts, blob + boff[0], N, H, W, ci0, 2, st, warp))) return rc;
+  if ((rc = c3_fwd_t<T>(x0, nullptr, acts, blob + boff[0], N, H, W, ci0, 2, st, warp, dir))) return rc;
   for (int i = 0; i < nb; ++i) {
     if constexpr (sizeof(T) == 2) {                    // one launch per residual block
       const C3Grid g = c3_grid(N, H, W);
       hipLaunchKernelGGL((c3_resblock_fwd_kernel<T>), g.grid, dim3(64 * C3Pair::NPT_H), 0, st, acts + i * act, mids + i * act,
-                         acts + (i + 1) * act, blob + boff[1 + 2 * i], blob + boff[2 + 2 * i], H, W, g.tx);
+                         acts + (i + 1) * act, blob + boff[1 + 2 * i], blob + boff[2 + 2 * i], H, W, g.tx, dir);
       SR_HIP_CHECK_LAUNCH();
       continue;
     }
-    if ((rc = c3_fwd_t<T>(acts + i * act, nullptr, mids + i * act, blob + boff[1 + 2 * i], N, H, W, 24, 1, st))) return rc;
-    if ((rc = c3_fwd_t<T>(mids + i * act, acts + i * act, acts + (i + 1) * act, blob + boff[2 + 2 * i], N, H, W, 24, 0, st)))
+    if ((rc = c3_fwd_t<T>(acts + i * act, nullptr, mids + i * act, blob + boff[1 + 2 * i], N, H, W, 24, 1, st, nullptr, dir))) return rc;
+    if ((rc = c3_fwd_t<T>(mids + i * act, acts + i * act, acts + (i + 1) * act, blob + boff[2 + 2 * i], N, H, W, 24, 0, st, nullptr, dir)))
       return rc;
   }
   return 0;
@@ -559,7 +559,7 @@ static int c3_trunk_fwd_t(const void* x0, const sr_c3_warp_t* warp, void* acts_,
 template <typename T>
 static int c3_trunk_bwd_t(const void* x0, const sr_c3_warp_t* warp, const void* acts_, const void* mids_, void* ga_, void* gt_,
                           const void* blob_, const long* boff, float* parts, void* dx0, const sr_c3_unpack_t* up, int nb,
-                          int wgs, int N, int H, int W, int ci0, hipStream_t st) {
+                          int wgs, int N, int H, int W, int ci0, hipStream_t st, C3Dir dir) {
   const size_t act = (size_t)N * H * W * 24;
   const T* acts = (const T*)acts_; const T* mids = (const T*)mids_; const T* blob = (const T*)blob_;
   T* ga = (T*)ga_; T* gt = (T*)gt_;
@@ -569,25 +569,28 @@ static int c3_trunk_bwd_t(const void* x0, const sr_c3_warp_t* warp, const void* 
     if constexpr (sizeof(T) == 2) {
       const C3Grid g = c3_grid(N, H, W);
       hipLaunchKernelGGL((c3_resblock_bwd_data_kernel<T>), g.grid, dim3(64 * C3Pair::NPT_H), 0, st, ga + (i + 1) * act,
-                         mids + i * act, gt + i * act, ga + i * act, blob + boff[1 + 2 * i], blob + boff[2 + 2 * i], H, W, g.tx);
+                         mids + i * act, gt + i * act, ga + i * act, blob + boff[1 + 2 * i], blob + boff[2 + 2 * i], H, W, g.tx, dir);
       SR_HIP_CHECK_LAUNCH();
       continue;
     }
-    if ((rc = c3_bwd_t<T>(ga + (i + 1) * act, ga + (i + 1) * act, nullptr, gt + i * act, blob + boff[2 + 2 * i], N, H, W, 24, 0, st)))
+    if ((rc = c3_bwd_t<T>(ga + (i + 1) * act, ga + (i + 1) * act, nullptr, gt + i * act, blob + boff[2 + 2 * i], N, H, W, 24, 0, st, dir)))
       return rc;
-    if ((rc = c3_bwd_t<T>(gt + i * act, mids + i * act, ga + (i + 1) * act, ga + i * act, blob + boff[1 + 2 * i], N, H, W, 24, 1, st)))
+    if ((rc = c3_bwd_t<T>(gt + i * act, mids + i * act, ga + (i + 1) * act, ga + i * act, blob + boff[1 + 2 * i], N, H, W, 24, 1, st, dir)))
       return rc;
   }
   if (nb > 0) {                                      // every conv2, then every conv1, one launch each
     if ((rc = c3_wgrad_t<T>(mids, ga + act, ga + act, parts + 2 * slot, wgs, N, H, W, 24, 0, st, nb, (long)act, (long)act,
-                            (long)act, 2 * slot)))
+                            (long)act, 2 * slot, nullptr, dir.n_dir)))
       return rc;
-    if ((rc = c3_wgrad_t<T>(acts, gt, mids, parts + slot, wgs, N, H, W, 24, 1, st, nb, (long)act, (long)act, (long)act, 2 * slot)))
+    if ((rc = c3_wgrad_t<T>(acts, gt, mids, parts + slot, wgs, N, H, W, 24, 1, st, nb, (long)act, (long)act, (long)act, 2 * slot,
+                            nullptr, dir.n_dir)))
       return rc;
   }
   const bool regather = warp && !warp->x0_save;      // the forward kept the gathered input unless told not to
-  if ((rc = c3_wgrad_t<T>(warp && !regather ? warp->x0_save : x0, ga, acts, parts, wgs, N, H, W, ci0, 2, st, 1, 0, 0, 0, 0, regather ? warp : nullptr))) return rc;
-  if (dx0 && (rc = c3_bwd_t<T>(ga, acts, nullptr, dx0, blob + boff[0], N, H, W, ci0, 2, st))) return rc;
+  if ((rc = c3_wgrad_t<T>(warp && !regather ? warp->x0_save : x0, ga, acts, parts, wgs, N, H, W, ci0, 2, st, 1, 0, 0, 0, 0, regather ? warp : nullptr,
+                          dir.n_dir)))
+    return rc;
+  if (dx0 && (rc = c3_bwd_t<T>(ga, acts, nullptr, dx0, blob + boff[0], N, H, W, ci0, 2, st, dir))) return rc;
   if (warp && (warp->dstate || warp->dflow)) {       // flow_warp backward, gather form (no float atomics)
     if (!dx0 || !warp->dstate || (warp->flow && !warp->flow_bound)) return -2;
     const int tx = (W + C3WarpBwd::TS - 1) / C3WarpBwd::TS, ty = (H + C3WarpBwd::TS - 1) / C3WarpBwd::TS;
@@ -595,15 +598,22 @@ static int c3_trunk_bwd_t(const void* x0, const sr_c3_warp_t* warp, const void* 
                        warp->flow_bound, (T*)warp->dstate, warp->dflow, warp->dflow_bs, H, W, tx);
     SR_HIP_CHECK_LAUNCH();
   }
-  if (up) {                                          // slabs -> gradient of the flat parameter
+  if (up) {                                          // slabs -> gradient of the flat parameter (of each trunk: its half of the slabs)
     UnpackSegs us;
     const long slab = 9 * 1024;
+    const int ndir = dir.n_dir > 0 ? 2 : 1, wd = wgs / ndir;
+    const long total = (long)up->n0 + (nb > 0 ? 2L * nb * up->n1 : 0);
     us.nseg = 0;
-    int blk = (up->n0 + 63) / 64;
-    us.s[us.nseg++] = UnpackSeg{parts, up->sidx0, up->dst0, 0, 0, slab, wgs, up->n0, 1, 0};
-    if (nb > 0) {
-      us.s[us.nseg++] = UnpackSeg{parts + (size_t)wgs * slab, up->sidx1, up->dst1, (long)up->n0, (long)up->n1, slab, wgs, up->n1, 2 * nb, blk};
-      blk += 2 * nb * ((up->n1 + 63) / 64);
+    int blk = 0;
+    for (int d = 0; d < ndir; ++d) {
+      us.s[us.nseg++] = UnpackSeg{parts + (size_t)d * wd * slab, up->sidx0, up->dst0, d * total, 0, slab, wd, up->n0, 1, blk, wgs};
+      blk += (up->n0 + 63) / 64;
+      if (nb > 0) {
+        // layer l's slabs start at parts + (1 + l) wgs slab: the stride between layers stays wgs slabs, this trunk's start d wd slabs in
+        us.s[us.nseg++] = UnpackSeg{parts + (size_t)wgs * slab + (size_t)d * wd * slab, up->sidx1, up->dst1, d * total + (long)up->n0,
+                                    (long)up->n1, slab, wd, up->n1, 2 * nb, blk, wgs};
+        blk += 2 * nb * ((up->n1 + 63) / 64);
+      }
     }
     hipLaunchKernelGGL(unpack_all_kernel, dim3(blk), dim3(64 * UNPACK_Q), 0, st, up->gflat, us);
     SR_HIP_CHECK_LAUNCH();
@@ -611,15 +621,19 @@ static int c3_trunk_bwd_t(const void* x0, const sr_c3_warp_t* warp, const void* 
   return 0;
 }
 extern "C" int sr_c3_trunk_fwd(const void* x0, const sr_c3_warp_t* warp, void* acts, void* mids, const void* blob,
-                               const long* blob_off, int nb, int N, int H, int W, int ci0, int dtype, sr_stream_t stream) {
+                               const long* blob_off, int nb, int N, int H, int W, int ci0, int dtype, int n_dir, long blob_dir_stride,
+                               sr_stream_t stream) {
   if ((!x0) == (!warp) || !acts || (nb > 0 && !mids) || !blob || !blob_off || nb < 0 || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
   if (warp && (!warp->frame || ci0 != 32 || (warp->flow && !warp->state))) return -2;
-  return dtype == SR_DTYPE_BF16 ? c3_trunk_fwd_t<__bf16>(x0, warp, acts, mids, blob, blob_off, nb, N, H, W, ci0, (hipStream_t)stream)
-                                : c3_trunk_fwd_t<float>(x0, warp, acts, mids, blob, blob_off, nb, N, H, W, ci0, (hipStream_t)stream);
+  if (n_dir < 0 || n_dir >= N) return -2;
+  const C3Dir dir{blob_dir_stride, n_dir};
+  return dtype == SR_DTYPE_BF16 ? c3_trunk_fwd_t<__bf16>(x0, warp, acts, mids, blob, blob_off, nb, N, H, W, ci0, (hipStream_t)stream, dir)
+                                : c3_trunk_fwd_t<float>(x0, warp, acts, mids, blob, blob_off, nb, N, H, W, ci0, (hipStream_t)stream, dir);
 }
 extern "C" int sr_c3_trunk_bwd(const void* x0, const sr_c3_warp_t* warp, const void* acts, const void* mids, void* ga, void* gt,
                                const void* blob, const long* blob_off, float* parts, void* dx0, const sr_c3_unpack_t* unpack,
-                               int nb, int wgs, int N, int H, int W, int ci0, int dtype, sr_stream_t stream) {
+                               int nb, int wgs, int N, int H, int W, int ci0, int dtype, int n_dir, long blob_dir_stride,
+                               sr_stream_t stream) {
   if ((!x0) == (!warp) || !acts || !ga || (nb > 0 && (!mids || !gt)) || !blob || !blob_off || !parts || nb < 0 || wgs <= 0 || N <= 0 ||
       H <= 0 || W <= 0 || N > 65535)
     return -2;
@@ -627,9 +641,11 @@ extern "C" int sr_c3_trunk_bwd(const void* x0, const sr_c3_warp_t* warp, const v
   if (unpack && (!unpack->sidx0 || !unpack->dst0 || !unpack->gflat || unpack->n0 <= 0 ||
                  (nb > 0 && (!unpack->sidx1 || !unpack->dst1 || unpack->n1 <= 0))))
     return -2;
+  if (n_dir < 0 || n_dir >= N || (n_dir > 0 && (wgs & 1))) return -2;
+  const C3Dir dir{blob_dir_stride, n_dir};
   return dtype == SR_DTYPE_BF16
-             ? c3_trunk_bwd_t<__bf16>(x0, warp, acts, mids, ga, gt, blob, blob_off, parts, dx0, unpack, nb, wgs, N, H, W, ci0, (hipStream_t)stream)
-             : c3_trunk_bwd_t<float>(x0, warp, acts, mids, ga, gt, blob, blob_off, parts, dx0, unpack, nb, wgs, N, H, W, ci0, (hipStream_t)stream);
+             ? c3_trunk_bwd_t<__bf16>(x0, warp, acts, mids, ga, gt, blob, blob_off, parts, dx0, unpack, nb, wgs, N, H, W, ci0, (hipStream_t)stream, dir)
+             : c3_trunk_bwd_t<float>(x0, warp, acts, mids, ga, gt, blob, blob_off, parts, dx0, unpack, nb, wgs, N, H, W, ci0, (hipStream_t)stream, dir);
 }
 
 // ------------------------------------------------------------------------------------------

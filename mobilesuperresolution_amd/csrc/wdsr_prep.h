@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
   else reinterpret_cast<T*>(sg.out)[(size_t)rep * sg.n + i] = (T)v;
 }
 
-struct UnpackSeg { const float* partial; const int* sidx; const int* dst; long dst_off, dst_stride, slab; int wgs, n, reps, block0; };
+// (rep_wgs: slabs between two reps' first slab when a segment sums only part of a rep's slabs -- two trunks in one launch; 0 = wgs)
+struct UnpackSeg { const float* partial; const int* sidx; const int* dst; long dst_off, dst_stride, slab; int wgs, n, reps, block0, rep_wgs; };
 struct UnpackSegs { UnpackSeg s[4]; int nseg; };
 
 constexpr int UNPACK_Q = 16;                             // slab groups per block: 64 elements x 16 partial sums
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(64 * UNPACK_Q) void unpack_all_kernel(float* __rest
   const int e = threadIdx.x & 63, q = threadIdx.x >> 6, i = (b - rep * per_rep) * 64 + e;
   float acc = 0.f;
   if (rep < sg.reps && i < sg.n) {
-    const float* p = sg.partial + (size_t)rep * sg.wgs * sg.slab + sg.sidx[i];
+    const float* p = sg.partial + (size_t)rep * (sg.rep_wgs ? sg.rep_wgs : sg.wgs) * sg.slab + sg.sidx[i];
 #pragma unroll 8                                     // many slabs (tail / head): keep the loads in flight
     for (int w = q; w < sg.wgs; w += UNPACK_Q) acc += p[(size_t)w * sg.slab];
   }

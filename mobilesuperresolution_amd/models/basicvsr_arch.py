@@ -238,6 +238,22 @@ class ConvResidualBlocks(nn.Module):
         return _TrunkWarpFunction.apply(frame, state, flow, flow_bound, self, self.flat)
 
 
+def forward_warped_pair(trunk_a, trunk_b, frames, state=None, flow=None, flow_bound=None):
+    """ONE recurrent step of BOTH propagation directions (reference: the two loops of basicvsr_arch.py:67-88, which are
+    independent of each other): frames (2N, 3, H, W) = [the backward-time loop's frame | the forward-time loop's frame], state / flow
+    likewise (2N, ...); the first half runs through `trunk_a`, the second through `trunk_b`, in the same launches -- twice the
+    workgroups per launch and half the dependent launches of two forward_warped calls.  Returns (features (2N, F, H, W), state)."""
+    if flow is not None and flow_bound is None:
+        flow_bound = flow.detach().abs().amax()
+    feat, new_state = _TrunkWarpFunction.apply(frames, state, flow, flow_bound, trunk_a, trunk_a.flat, trunk_b, trunk_b.flat)
+    half = frames.shape[0] // 2
+    for tr, sl in ((trunk_a, slice(0, half)), (trunk_b, slice(half, None))):
+        for hook in tr._forward_hooks.values():       # forward hooks of the two modules see their half of the step, as with forward_warped
+            hook(tr, (frames[sl], None if state is None else state[sl], None if flow is None else flow[sl], flow_bound),
+                 (feat[sl], new_state[sl]))
+    return feat, new_state
+
+
 def _wgrad_wgs(n, h, w, cap=72):
     """workgroups per conv for the weight-gradient launches: every workgroup walks the same number of 12x24 tiles (144 tiles
     at C4 -> 72 workgroups x 2 tiles; 64 workgroups left a quarter of them idle in the third round)"""
@@ -269,7 +285,7 @@ class _TrunkFunction(torch.autograd.Function):
         acts = torch.empty((nb + 1, n, h, w, 24), dtype=dt, device=dev)              # a_0 .. a_nb
         mids = torch.empty((max(nb, 1), n, h, w, 24), dtype=dt, device=dev)          # t_i = relu(conv1(a_i))
         _launch("sr_c3_trunk_fwd", x0.data_ptr(), None, acts.data_ptr(), mids.data_ptr(), blob.data_ptr(), tabs[2], nb, n, h, w,
-                ci0, L.DTYPE_CODE[dt])
+                ci0, L.DTYPE_CODE[dt], 0, 0)
         ctx.mod, ctx.x0, ctx.acts, ctx.mids, ctx.blob = mod, x0, acts, mids, blob
         ctx.need_dx = fea.requires_grad
         out = torch.empty((n, mod.num_feat, h, w), dtype=torch.float32, device=dev)
@@ -304,7 +320,7 @@ class _TrunkFunction(torch.autograd.Function):
         unpack = L.C3Unpack(s0.data_ptr(), d0.data_ptr(), s0.numel(), s1.data_ptr(), d1.data_ptr(), s1.numel(), gflat.data_ptr())
         _launch("sr_c3_trunk_bwd", x0.data_ptr(), None, acts.data_ptr(), mids.data_ptr(), ga.data_ptr(), gt.data_ptr(),
                 blob.data_ptr(), boff, parts.data_ptr(), dx0.data_ptr() if dx0 is not None else None, ctypes.byref(unpack), nb, wgs,
-                n, h, w, ci0, L.DTYPE_CODE[dt])
+                n, h, w, ci0, L.DTYPE_CODE[dt], 0, 0)
         dfea = None
         if dx0 is not None:
             dfea = torch.empty((n, cin, h, w), dtype=torch.float32, device=dev)
@@ -320,12 +336,24 @@ def _inner_contiguous(t):
     return t if t.stride()[1:] == (h * w, w, 1) else t.contiguous()
 
 
+def _pair_blob(mod, flat, mod2, flat2):
+    """the two trunks' packed weights one behind the other (cached until either parameter changes)"""
+    b1, b2 = mod._packed(flat), mod2._packed(flat2)
+    key = (b1.data_ptr(), mod._blob_key, b2.data_ptr(), mod2._blob_key)
+    if getattr(mod, "_pair_key", None) != key:
+        mod._pair_blob_t = torch.cat([b1, b2])
+        mod._pair_key = key
+    return mod._pair_blob_t, b1.numel()
+
+
 class _TrunkWarpFunction(torch.autograd.Function):
     """flow_warp -> concat -> whole trunk, forward / backward as one C call each (sr_c3_trunk_fwd / _bwd with a
-    sr_c3_warp_t): outputs (features NCHW fp32, the same features NHWC in the hot dtype = the next call's state)"""
+    sr_c3_warp_t): outputs (features NCHW fp32, the same features NHWC in the hot dtype = the next call's state).
+    With `mod2` / `flat2`: TWO trunks in the same launches -- the first half of the batch through `mod`, the second half through
+    `mod2` (the two time directions of a frame step of the propagation loops, which are independent)."""
 
     @staticmethod
-    def forward(ctx, frame, state, flow, bound, mod, flat):
+    def forward(ctx, frame, state, flow, bound, mod, flat, mod2=None, flat2=None):
         import ctypes
         dt, nb = mod.hot_dtype, mod.num_block
         n, _, h, w = frame.shape
@@ -339,20 +367,27 @@ class _TrunkWarpFunction(torch.autograd.Function):
             raise ValueError(f"expected N x 2 x H x W flow, got {tuple(flow_.shape)}")
         bound_ = bound.detach().float().reshape(()) if bound is not None else None
         with torch.cuda.device(dev):
-            blob = mod._packed(flat)
+            if mod2 is None:
+                blob, n_dir, bstride = mod._packed(flat), 0, 0
+            else:
+                if n % 2 or (mod2.num_block, mod2.hot_dtype, mod2.num_feat, mod2.cin_k) != (nb, dt, mod.num_feat, mod.cin_k):
+                    raise ValueError("two trunks in one call: an even batch (one half per trunk) and trunks of the same geometry")
+                blob, bstride = _pair_blob(mod, flat, mod2, flat2)
+                n_dir = n // 2
             tabs = _trunk_tables(27, nb, dev.index)
             acts = torch.empty((nb + 1, n, h, w, 24), dtype=dt, device=dev)
             mids = torch.empty((max(nb, 1), n, h, w, 24), dtype=dt, device=dev)
             # the gathered input is kept (2 MB at C4) when a backward will want the first conv's weight gradient
-            x0 = torch.empty((n, h, w, 32), dtype=dt, device=dev) if ctx.needs_input_grad[5] else None
+            x0 = torch.empty((n, h, w, 32), dtype=dt, device=dev) if (ctx.needs_input_grad[5] or (mod2 is not None and ctx.needs_input_grad[7])) else None
             warp = L.C3Warp(frame_.data_ptr(), frame_.stride(0), state_.data_ptr() if state_ is not None else None,
                             flow_.data_ptr() if flow_ is not None else None, flow_.stride(0) if flow_ is not None else 0,
                             None, None, None, 0, x0.data_ptr() if x0 is not None else None)
             _launch("sr_c3_trunk_fwd", None, ctypes.byref(warp), acts.data_ptr(), mids.data_ptr(), blob.data_ptr(), tabs[2], nb,
-                    n, h, w, 32, L.DTYPE_CODE[dt])
+                    n, h, w, 32, L.DTYPE_CODE[dt], n_dir, bstride)
             out = torch.empty((n, mod.num_feat, h, w), dtype=torch.float32, device=dev)
             out.copy_(acts[nb][..., :mod.num_feat].permute(0, 3, 1, 2))
         ctx.mod, ctx.acts, ctx.mids, ctx.blob, ctx.x0 = mod, acts, mids, blob, x0
+        ctx.mod2, ctx.n_dir, ctx.bstride = mod2, n_dir, bstride
         ctx.frame, ctx.state, ctx.flow, ctx.bound = frame_, state_, flow_, bound_
         ctx.need = (frame.requires_grad, state is not None and state.requires_grad, flow is not None and flow.requires_grad)
         ctx.set_materialize_grads(False)
@@ -367,7 +402,8 @@ class _TrunkWarpFunction(torch.autograd.Function):
         _, n, h, w, _ = acts.shape
         dev = acts.device
         need_frame, need_state, need_flow = ctx.need
-        wgs = _wgrad_wgs(n, h, w)
+        n_dir, bstride, mod2 = ctx.n_dir, ctx.bstride, ctx.mod2
+        wgs = _wgrad_wgs(n, h, w) if not n_dir else 2 * _wgrad_wgs(n_dir, h, w)
         with torch.cuda.device(dev):
             _, _, boff, _ = _trunk_tables(27, nb, dev.index)
             s0, d0, s1, d1 = _unpack_tables(27, dev.index)
@@ -401,15 +437,18 @@ class _TrunkWarpFunction(torch.autograd.Function):
                             dflow.data_ptr() if dflow is not None else None, 2 * h * w,
                             ctx.x0.data_ptr() if ctx.x0 is not None else None)
             total = s0.numel() + 2 * nb * s1.numel()
-            gflat = torch.empty(total, dtype=torch.float32, device=dev)
+            gflat = torch.empty(total * (2 if n_dir else 1), dtype=torch.float32, device=dev)
             unpack = L.C3Unpack(s0.data_ptr(), d0.data_ptr(), s0.numel(), s1.data_ptr(), d1.data_ptr(), s1.numel(), gflat.data_ptr())
             _launch("sr_c3_trunk_bwd", None, ctypes.byref(warp), acts.data_ptr(), mids.data_ptr(), ga.data_ptr(), gt.data_ptr(),
                     blob.data_ptr(), boff, parts.data_ptr(), dx0.data_ptr() if dx0 is not None else None, ctypes.byref(unpack),
-                    nb, wgs, n, h, w, 32, L.DTYPE_CODE[dt])
+                    nb, wgs, n, h, w, 32, L.DTYPE_CODE[dt], n_dir, bstride)
             dframe = dx0[..., :3].permute(0, 3, 1, 2).float() if need_frame else None
+            g1, g2 = (gflat[:total], gflat[total:]) if n_dir else (gflat, None)
             if mod._pad:
-                gflat = gflat.index_select(0, mod._unpad_idx)
-        return dframe, (dstate if need_state else None), dflow, None, None, gflat
+                g1 = g1.index_select(0, mod._unpad_idx)
+                if g2 is not None:
+                    g2 = g2.index_select(0, mod2._unpad_idx)
+        return dframe, (dstate if need_state else None), dflow, None, None, g1, None, g2
 
 
 _SIDE = {}
@@ -441,6 +480,19 @@ def propagate(x, flows_forward, flows_backward, backward_trunk, forward_trunk, f
         # 8 clips of 64x64): the backward-time loop runs on a side stream, the forward-time loop on the caller's; autograd
         # replays each node's backward on the stream its forward ran on.  Opt-in (SR_VSR_TWO_STREAMS=1): at C4 the step is bound
         # by host issue, and the stream switches cost more host time (2.24 -> 2.63 ms) than the overlap returns.
+        same = (backward_trunk.num_block, backward_trunk.hot_dtype, backward_trunk.num_feat) == (forward_trunk.num_block, forward_trunk.hot_dtype,
+                                                                                                 forward_trunk.num_feat)
+        if same and backward_trunk is not forward_trunk and os.environ.get("SR_VSR_SEPARATE_DIRECTIONS", "0") != "1":
+            # both directions of a frame step in ONE set of launches (round 3): step k = the backward-time loop's frame n - 1 - k next to
+            # the forward-time loop's frame k, batched; the trunk kernels pick the weights by batch half
+            xp = torch.cat([x.flip(1), x], 0)
+            fl = torch.cat([flows_backward.flip(1), flows_forward], 0) if n > 1 else None
+            state = None
+            for k in range(n):
+                feat, state = forward_warped_pair(backward_trunk, forward_trunk, xp[:, k], state, fl[:, k - 1] if k > 0 else None, bound)
+                out_b.insert(0, feat[:b])
+                out_f.append(feat[b:])
+            return out_b, out_f
         cur = torch.cuda.current_stream(x.device)
         side = _side_stream(x.device) if os.environ.get("SR_VSR_TWO_STREAMS", "0") == "1" else cur
         if side is not cur:
