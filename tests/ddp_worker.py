@@ -115,6 +115,7 @@ def fused_mode(args, ns, rank, world, overlap=False):
         rf = ref.flat.detach().cpu()
         json.dump({"replicas_equal": all(torch.equal(gathered[0], t) for t in gathered[1:]),
                    "param_err": (mine - rf).abs().max().item(), "param_scale": rf.abs().max().item(),
+                   "param_bad_frac": ((mine - rf).abs() > 2e-5 * rf.abs().max() + 2e-6).float().mean().item(), "lr": 1e-3 * world,
                    "loss_rank0": losses, "loss_full": ref_losses}, open(args.out, "w"))
     dist.barrier()
     dist.destroy_process_group()

@@ -312,6 +312,13 @@ def test_block_pair_bwd_data_matches_two_launches_and_torch(shape):
                                             None, None, n, h, w, f, 1, L.stream_ptr()), "pair bwd, no dt")
     torch.cuda.synchronize()
     assert torch.equal(p1, q1) and torch.equal(p0, q0)                 # (with and without the saved images)
+    if n > 1:                                                          # an image's result does not depend on its batch
+        s1, s0 = torch.full_like(xa[-1:], float("nan")), torch.full_like(xa[-1:], float("nan"))
+        L.check(L.lib().sr_wdsr_block2_bwd_data(xa[-1:].data_ptr(), xb[-1:].data_ptr(), dyb[-1:].data_ptr(), s1.data_ptr(), s0.data_ptr(),
+                                                blob[0].data_ptr(), blob[1].data_ptr(), cinit[0].data_ptr(), cinit[1].data_ptr(),
+                                                None, None, 1, h, w, f, 1, L.stream_ptr()), "pair bwd, last image alone")
+        torch.cuda.synchronize()
+        assert torch.equal(s1, p1[-1:]) and torch.equal(s0, p0[-1:])
     _assert_same_up_to_summation_order(p1, d1, "dx of block b")
     _assert_same_up_to_summation_order(p0, d0, "dx of block a")
     # the saved dt images: dt = conv_transpose(dy, W3) on bf16 operands, tile-local [tile 12 x 24][288][24] with zeros in channels 20..23

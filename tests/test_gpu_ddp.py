@@ -71,7 +71,10 @@ def test_fused_data_parallel_train_step_two_ranks(tmp_path, mode):
     stay bit-equal, parameters match the full-batch run"""
     res = _run_two_ranks(tmp_path, mode)
     assert res["replicas_equal"], res
-    assert res["param_err"] <= 2e-5 * res["param_scale"] + 2e-6, res      # Adam's first steps amplify fp32 summation-order ulps
+    # Adam's first steps move every parameter by ~lr whatever the gradient's size, so a gradient that is zero up to fp32 summation
+    # order (the two ranks sum their weight gradients in another grouping) may step the other way: the bulk must agree closely, a
+    # stray parameter may differ by a fraction of the three steps' 3 lr
+    assert res["param_bad_frac"] <= 1e-3 and res["param_err"] <= 0.1 * 3 * res["lr"], res
     assert all(abs(a) > 0 for a in res["loss_rank0"])
 
 
