@@ -607,12 +607,12 @@ static int c3_trunk_bwd_t(const void* x0, const sr_c3_warp_t* warp, const void* 
     int blk = 0;
     for (int d = 0; d < ndir; ++d) {
       us.s[us.nseg++] = UnpackSeg{parts + (size_t)d * wd * slab, up->sidx0, up->dst0, d * total, 0, slab, wd, up->n0, 1, blk, wgs};
-      blk += (up->n0 + 63) / 64;
+      blk += unpack_blocks(up->n0, wd);
       if (nb > 0) {
         // layer l's slabs start at parts + (1 + l) wgs slab: the stride between layers stays wgs slabs, this trunk's start d wd slabs in
         us.s[us.nseg++] = UnpackSeg{parts + (size_t)wgs * slab + (size_t)d * wd * slab, up->sidx1, up->dst1, d * total + (long)up->n0,
                                     (long)up->n1, slab, wd, up->n1, 2 * nb, blk, wgs};
-        blk += 2 * nb * ((up->n1 + 63) / 64);
+        blk += 2 * nb * unpack_blocks(up->n1, wd);
       }
     }
     hipLaunchKernelGGL(unpack_all_kernel, dim3(blk), dim3(64 * UNPACK_Q), 0, st, up->gflat, us);
@@ -975,7 +975,7 @@ static int net_backward_part_impl(const sr_wdsr_net_t* n, int part, sr_stream_t 
     auto add = [&](const float* part_, const int* sidx, const int* dst, long off, long stride, long slab, int wgs, int cnt,
                    int reps) {
       us.s[us.nseg++] = UnpackSeg{part_, sidx, dst, off, stride, slab, wgs, cnt, reps, blk};
-      blk += reps * ((cnt + 63) / 64);
+      blk += reps * unpack_blocks(cnt, wgs);
     };
     if (nl > 0) {
       add(n->part_a, n->ga_sidx, n->ga_dst, n->src_body_off + b0 * n->src_body_stride, n->src_body_stride, n->slab_a, wgs_part,
@@ -1045,7 +1045,7 @@ extern "C" int sr_param_grads(const float* flat, float* dsrc, float* gflat, cons
     const sr_unpack_seg_t& g = segs[k];
     if (!g.partial || !g.sidx || !g.dst || g.n <= 0 || g.reps <= 0 || g.wgs <= 0) return -2;
     us.s[k] = UnpackSeg{g.partial, g.sidx, g.dst, g.dst_off, g.dst_stride, g.slab, g.wgs, g.n, g.reps, blk};
-    blk += g.reps * ((g.n + 63) / 64);
+    blk += g.reps * unpack_blocks(g.n, g.wgs);
   }
   hipLaunchKernelGGL(unpack_all_kernel, dim3(blk), dim3(64 * UNPACK_Q), 0, st, dsrc, us);
   const int cb = (n_chan + 3) / 4, bb = (n_bias + 255) / 256;

@@ -125,28 +125,59 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
 struct UnpackSeg { const float* partial; const int* sidx; const int* dst; long dst_off, dst_stride, slab; int wgs, n, reps, block0, rep_wgs; };
 struct UnpackSegs { UnpackSeg s[4]; int nseg; };
 
-constexpr int UNPACK_Q = 16;                             // slab groups per block: 64 elements x 16 partial sums
+constexpr int UNPACK_Q = 16;                             // slab groups per block: 16 partial sums per element
+// Elements per block.  Few slabs per element (the body layers: 16): a thread has ONE load per element, so it takes four elements
+// (four independent loads in flight; one element per thread was 3 600 blocks of one dependent load each at C2).  Many slabs (tail,
+// head: 256): a thread's 16 loads of one element are independent already and the segment has few elements -- 64 per block
+// spreads it over four times the CUs.
+constexpr int UNPACK_JMAX = 4;
+constexpr int unpack_j(int wgs) { return wgs > 4 * UNPACK_Q ? 1 : UNPACK_JMAX; }
+constexpr int unpack_blocks(int n, int wgs) { return (n + 64 * unpack_j(wgs) - 1) / (64 * unpack_j(wgs)); }
+
+template <int J>
+__device__ __forceinline__ void unpack_body(float* __restrict__ dsrc, const UnpackSeg& sg, float (*red)[64 * UNPACK_JMAX]) {
+  constexpr int E = 64 * J;
+  const int per_rep = (sg.n + E - 1) / E;
+  const int b = blockIdx.x - sg.block0, rep = b / per_rep;
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6, i0 = (b - rep * per_rep) * E + e;
+  float acc[J];
+  const float* p[J];
+  const float* const base = sg.partial + (size_t)rep * (sg.rep_wgs ? sg.rep_wgs : sg.wgs) * sg.slab;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int i = i0 + 64 * j;
+    acc[j] = 0.f;
+    p[j] = base + (rep < sg.reps && i < sg.n ? sg.sidx[i] : 0);
+  }
+  if (rep < sg.reps) {
+#pragma unroll(J == 1 ? 16 : 4)                      // keep the loads in flight
+    for (int w = q; w < sg.wgs; w += UNPACK_Q) {
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+        if (i0 + 64 * j < sg.n) acc[j] += p[j][(size_t)w * sg.slab];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < J; ++j) red[q][e + 64 * j] = acc[j];
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < E && rep < sg.reps) {
+    const int i = (b - rep * per_rep) * E + t;
+    if (i < sg.n) {
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < UNPACK_Q; ++j) v += red[j][t];
+      dsrc[sg.dst_off + (size_t)rep * sg.dst_stride + sg.dst[i]] = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(64 * UNPACK_Q) void unpack_all_kernel(float* __restrict__ dsrc, UnpackSegs segs) {
-  __shared__ float red[UNPACK_Q][64];
+  __shared__ float red[UNPACK_Q][64 * UNPACK_JMAX];
   int k = 0;
 #pragma unroll
   for (int i = 1; i < 4; ++i) if (i < segs.nseg && (int)blockIdx.x >= segs.s[i].block0) k = i;
   const UnpackSeg sg = segs.s[k];
-  const int per_rep = (sg.n + 63) / 64;
-  const int b = blockIdx.x - sg.block0, rep = b / per_rep;
-  const int e = threadIdx.x & 63, q = threadIdx.x >> 6, i = (b - rep * per_rep) * 64 + e;
-  float acc = 0.f;
-  if (rep < sg.reps && i < sg.n) {
-    const float* p = sg.partial + (size_t)rep * (sg.rep_wgs ? sg.rep_wgs : sg.wgs) * sg.slab + sg.sidx[i];
-#pragma unroll 8                                     // many slabs (tail / head): keep the loads in flight
-    for (int w = q; w < sg.wgs; w += UNPACK_Q) acc += p[(size_t)w * sg.slab];
-  }
-  red[q][e] = acc;
-  __syncthreads();
-  if (q == 0 && rep < sg.reps && i < sg.n) {
-    float v = 0.f;
-#pragma unroll
-    for (int j = 0; j < UNPACK_Q; ++j) v += red[j][e];
-    dsrc[sg.dst_off + (size_t)rep * sg.dst_stride + sg.dst[i]] = v;
-  }
+  if (unpack_j(sg.wgs) == 1) unpack_body<1>(dsrc, sg, red);
+  else unpack_body<UNPACK_JMAX>(dsrc, sg, red);
 }
