@@ -366,6 +366,10 @@ typedef struct { float w_lerp, beta2, one_minus_beta2, bc2_sqrt, eps, neg_step_s
 int sr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, const sr_adam_t* a,
                  const float* loss_part, int n_loss, float loss_scale, float* loss_out, sr_stream_t stream);
 int sr_loss_value(const float* loss_part, int n_loss, float loss_scale, float* loss_out, sr_stream_t stream);
+/* y[i] = x[i] * (*scale), the product in fp32; x, y: n elements of `dtype`, 16-byte aligned; scale: a device scalar.  What
+   `loss_weight * criterion(sr, hr)` (search.py:74, pretrain.py:73) makes of a folded loss's data gradient: autograd hands the
+   weight over as a device tensor, torch's own multiply would round it to the gradient's dtype first. */
+int sr_scale_by(void* y, const void* x, long n, const float* scale, int dtype, sr_stream_t stream);
 /* forward + loss-folded backward + Adam in one call (net->hr etc. set; net->flat is updated in place). */
 int sr_wdsr_net_train_step(const sr_wdsr_net_t* net, float* exp_avg, float* exp_avg_sq, long n_params, const sr_adam_t* a,
                            float loss_scale, float* loss_out, sr_stream_t stream);

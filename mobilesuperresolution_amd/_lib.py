@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SR_HOTPATH_LIB_PATH (tools/ only): an explicitly named build of the same sources (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("SR_HOTPATH_LIB_PATH") or os.path.join(
     _HERE, "libsr_hotpath_dbg.so" if os.environ.get("SR_HOTPATH_DEBUG_LIB") == "1" else "libsr_hotpath.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
 
 _P, _I, _Z, _L, _F = c_void_p, c_int, c_size_t, ctypes.c_long, ctypes.c_float
@@ -65,6 +65,7 @@ SIGNATURES = {
     "sr_tail_bwd_loss": ([_P, _P, _I, _F, _P, _P, _P, _F, _P, _P, _P] + [_I] * 7 + [_P], _I),
     "sr_adam_step": ([_P, _P, _P, _P, _L, _P, _P, _I, _F, _P, _P], _I),
     "sr_loss_value": ([_P, _I, _F, _P, _P], _I),
+    "sr_scale_by": ([_P, _P, _L, _P, _I, _P], _I),
     "sr_wdsr_net_train_step": ([_P, _P, _P, _L, _P, _F, _P, _P], _I),
     "sr_wdsr_net_forward": ([_P, _I, _P], _I),
     "sr_wdsr_net_backward": ([_P, _P], _I),

@@ -20,7 +20,7 @@
 #include "train_step.h"
 #include "pixel_shuffle.h"
 
-extern "C" int sr_abi_version(void) { return 12; }
+extern "C" int sr_abi_version(void) { return 13; }
 
 // A/B switches between a kernel and the one it replaced are live in the diagnostic build only (build.py --debug); in the product
 // library they are the constant false, and the kernels only they reach are not instantiated.  (SR_NAS_FWD_SPLIT / SR_NAS_BWD_SPLIT
@@ -1230,6 +1230,17 @@ extern "C" int sr_adam_step(float* p, const float* g, float* m, float* v, long n
 extern "C" int sr_loss_value(const float* loss_part, int n_loss, float loss_scale, float* loss_out, sr_stream_t stream) {
   if (!loss_part || !loss_out || n_loss <= 0) return -2;
   hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_part, n_loss, loss_scale, loss_out);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int sr_scale_by(void* y, const void* x, long n, const float* scale, int dtype, sr_stream_t stream) {
+  if (!y || !x || !scale || n <= 0 || ((uintptr_t)y & 15) || ((uintptr_t)x & 15)) return -2;
+  const unsigned blocks = (unsigned)((n + 2047) / 2048);
+  if (dtype == SR_DTYPE_BF16)
+    hipLaunchKernelGGL(scale_by_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (__bf16*)y, (const __bf16*)x, n, scale);
+  else if (dtype == SR_DTYPE_F32)
+    hipLaunchKernelGGL(scale_by_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)y, (const float*)x, n, scale);
+  else return -1;
   SR_HIP_CHECK_LAUNCH();
   return 0;
 }

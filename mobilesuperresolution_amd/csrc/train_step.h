@@ -65,6 +65,23 @@ __global__ __launch_bounds__(64) void loss_sum_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) *loss_out = s * loss_scale;
 }
 
+// y = x * (*scale), the product formed in fp32 (a folded loss's data gradient times whatever the trainer multiplied the loss
+// with, which autograd hands over as a device scalar)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_by_kernel(T* __restrict__ y, const T* __restrict__ x, long n, const float* __restrict__ scale) {
+  const float s = *scale;
+  const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i0 + 8 <= n) {
+    typedef T V __attribute__((ext_vector_type(8)));
+    V v = *reinterpret_cast<const V*>(x + i0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (T)((float)v[j] * s);
+    *reinterpret_cast<V*>(y + i0) = v;
+  } else {
+    for (long i = i0; i < n; ++i) y[i] = (T)((float)x[i] * s);
+  }
+}
+
 // Weight-norm backward and the Adam step in ONE launch (single-process training step): a wave that has just produced the
 // gradient of its channel's v row and g (or a thread its bias entry's) applies the Adam update to exactly those
 // parameters -- every parameter of the network belongs to exactly one table row, so the separate pass over the flat

@@ -139,36 +139,45 @@ __device__ __forceinline__ void unpack_body(float* __restrict__ dsrc, const Unpa
   constexpr int E = 64 * J;
   const int per_rep = (sg.n + E - 1) / E;
   const int b = blockIdx.x - sg.block0, rep = b / per_rep;
+  if (rep >= sg.reps) return;                          // (block-uniform; the launch has exactly reps * per_rep blocks per segment)
   const int e = threadIdx.x & 63, q = threadIdx.x >> 6, i0 = (b - rep * per_rep) * E + e;
   float acc[J];
   const float* p[J];
   const float* const base = sg.partial + (size_t)rep * (sg.rep_wgs ? sg.rep_wgs : sg.wgs) * sg.slab;
+  // every load UNCONDITIONAL (an element past the segment's end re-reads the last one and is dropped at the store): a load
+  // under a per-lane condition is not hoisted, and the loop then waits for each one before issuing the next
 #pragma unroll
   for (int j = 0; j < J; ++j) {
-    const int i = i0 + 64 * j;
     acc[j] = 0.f;
-    p[j] = base + (rep < sg.reps && i < sg.n ? sg.sidx[i] : 0);
+    p[j] = base + sg.sidx[min(i0 + 64 * j, sg.n - 1)];
   }
-  if (rep < sg.reps) {
-#pragma unroll(J == 1 ? 16 : 4)                      // keep the loads in flight
-    for (int w = q; w < sg.wgs; w += UNPACK_Q) {
+  constexpr int U = J == 1 ? 16 : 4;
+  int w = q;
+  for (; w + (U - 1) * UNPACK_Q < sg.wgs; w += U * UNPACK_Q) {
+    float v[U][J];
 #pragma unroll
-      for (int j = 0; j < J; ++j)
-        if (i0 + 64 * j < sg.n) acc[j] += p[j][(size_t)w * sg.slab];
-    }
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < J; ++j) v[u][j] = p[j][(size_t)(w + u * UNPACK_Q) * sg.slab];
+#pragma unroll
+    for (int u = 0; u < U; ++u)                        // (summed in slab order: the order does not depend on U)
+#pragma unroll
+      for (int j = 0; j < J; ++j) acc[j] += v[u][j];
+  }
+  for (; w < sg.wgs; w += UNPACK_Q) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc[j] += p[j][(size_t)w * sg.slab];
   }
 #pragma unroll
   for (int j = 0; j < J; ++j) red[q][e + 64 * j] = acc[j];
   __syncthreads();
   const int t = threadIdx.x;
-  if (t < E && rep < sg.reps) {
-    const int i = (b - rep * per_rep) * E + t;
-    if (i < sg.n) {
-      float v = 0.f;
+  const int i = (b - rep * per_rep) * E + t;
+  if (t < E && i < sg.n) {
+    float v = 0.f;
 #pragma unroll
-      for (int j = 0; j < UNPACK_Q; ++j) v += red[j][t];
-      dsrc[sg.dst_off + (size_t)rep * sg.dst_stride + sg.dst[i]] = v;
-    }
+    for (int j = 0; j < UNPACK_Q; ++j) v += red[j][t];
+    dsrc[sg.dst_off + (size_t)rep * sg.dst_stride + sg.dst[i]] = v;
   }
 }
 

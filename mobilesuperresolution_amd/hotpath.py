@@ -184,6 +184,36 @@ def tail_wgrad(dout: torch.Tensor, feat: torch.Tensor, x: torch.Tensor, mean: fl
     return torch.cat([g, g.new_zeros(2)])
 
 
+def _tail_grad_vector(part: torch.Tensor, tb) -> torch.Tensor:
+    g = part.sum(0).index_select(0, tb["tail_grad"])
+    return torch.cat([g, g.new_zeros(2)])
+
+
+def tail_bwd(dout: torch.Tensor, feat: torch.Tensor, x: torch.Tensor, blob: torch.Tensor, mean: float, R: int, wgs: int = 256):
+    """tail_bwd_data + tail_wgrad in ONE launch (bf16: the gradient image is un-shuffled once for both): (dfeat, d_src_tail)"""
+    n, h, w, f = feat.shape
+    tb = ends_tables(f, R, feat.device)
+    part = torch.empty((wgs, tb["tail_slab"]), dtype=torch.float32, device=feat.device)
+    dfeat = torch.empty_like(feat)
+    _launch("sr_tail_bwd", L.lib().sr_tail_bwd, L.ptr(dout), L.ptr(feat), L.ptr(x), mean, L.ptr(blob), L.ptr(dfeat), L.ptr(part), wgs,
+            n, h, w, f, R, L.DTYPE_CODE[feat.dtype], L.stream_ptr())
+    return dfeat, _tail_grad_vector(part, tb)
+
+
+def tail_bwd_loss(out: torch.Tensor, hr: torch.Tensor, kind: int, gscale: float, feat: torch.Tensor, x: torch.Tensor,
+                  blob: torch.Tensor, mean: float, R: int, wgs: int = 256):
+    """the same with d(loss)/d(out) FORMED in the kernel from out and hr (kind 1: L1, 2: Charbonnier; gscale = upstream / numel):
+    (dfeat, d_src_tail, per-workgroup loss sums)"""
+    n, h, w, f = feat.shape
+    tb = ends_tables(f, R, feat.device)
+    part = torch.empty((wgs, tb["tail_slab"]), dtype=torch.float32, device=feat.device)
+    loss_part = torch.empty(wgs, dtype=torch.float32, device=feat.device)
+    dfeat = torch.empty_like(feat)
+    _launch("sr_tail_bwd_loss", L.lib().sr_tail_bwd_loss, L.ptr(out), L.ptr(hr), kind, gscale, L.ptr(loss_part), L.ptr(feat), L.ptr(x),
+            mean, L.ptr(blob), L.ptr(dfeat), L.ptr(part), wgs, n, h, w, f, R, L.DTYPE_CODE[feat.dtype], L.stream_ptr())
+    return dfeat, _tail_grad_vector(part, tb), loss_part
+
+
 def head_wgrad(dy0: torch.Tensor, x: torch.Tensor, mean: float, wgs: int = 64) -> torch.Tensor:
     n, h, w, f = dy0.shape
     tb = ends_tables(f, 4, dy0.device)

@@ -544,6 +544,10 @@ class _HeadFunction(torch.autograd.Function):
 
 
 class _TailFunction(torch.autograd.Function):
+    """tail conv + skip conv + PixelShuffle (reference wdsr_b.py:118-123).  A criterion of mobilesuperresolution_amd.training applied
+    to this node's output folds the loss into the tail-backward kernel (`fold_loss`): no d(loss)/d(out) tensor, none of the
+    seven small ATen loss kernels."""
+
     @staticmethod
     def forward(ctx, feat, x, wt, ws, btot, r, mean):
         n, h, w, f = feat.shape
@@ -552,18 +556,58 @@ class _TailFunction(torch.autograd.Function):
         HP.tail_fwd(feat, x, out, blob, mean, r)
         ctx.save_for_backward(feat, x, blob)
         ctx.r, ctx.mean, ctx.shapes = r, mean, (wt.shape, ws.shape)
+        ctx.out_ptr, ctx.folded, ctx.fold_loss, ctx.can_fold = out.data_ptr(), None, _TailFunction._fold_loss, _TailFunction._can_fold
         return out
 
+    _LOSS_KINDS = {"l1": 1, "charbonnier": 2}
+
     @staticmethod
-    def backward(ctx, dout):
-        feat, x, blob = ctx.saved_tensors
-        dout = dout.contiguous().float()
-        dfeat = torch.empty_like(feat)
-        HP.tail_bwd_data(dout, dfeat, blob, ctx.r)
-        g = HP.tail_wgrad(dout, feat, x, ctx.mean, ctx.r)
+    def _can_fold(node, sr, hr) -> bool:
+        return (sr.is_cuda and hr.is_cuda and hr.device == sr.device and sr.shape == hr.shape and sr.dtype == torch.float32
+                and sr.is_contiguous() and not hr.requires_grad and sr.data_ptr() == node.out_ptr)
+
+    @staticmethod
+    def _fold_loss(node, sr, hr, kind):
+        """run the tail's backward NOW with d(loss)/d(out) formed in the kernel (loss weight 1: the caller's scalar factors arrive
+        through autograd).  Returns (payload for backward(), loss partial sums)"""
+        feat, x, blob = node.saved_tensors
+        gscale = float(np.float32(1.0) / np.float32(sr.numel()))
+        with torch.cuda.device(sr.device):
+            dfeat, g, loss_part = HP.tail_bwd_loss(sr, hr, _TailFunction._LOSS_KINDS[kind], gscale, feat, x, blob, node.mean, node.r)
+        return (dfeat, g), loss_part
+
+    @staticmethod
+    def _split(ctx, dfeat, g):
         nt, ns = int(np.prod(ctx.shapes[0])), int(np.prod(ctx.shapes[1]))
         co = ctx.shapes[0][0]
         return dfeat, None, g[:nt].view(ctx.shapes[0]), g[nt:nt + ns].view(ctx.shapes[1]), g[nt + ns:nt + ns + co], None, None
+
+    @staticmethod
+    @_on_tensor_device
+    def backward(ctx, dout):
+        feat, x, blob = ctx.saved_tensors
+        folded = None
+        if ctx.folded is not None:
+            # the criterion has run this backward already; `dout` is its zero token (or the token plus the gradient of some
+            # OTHER use of the output, which then runs the usual way)
+            (dfeat0, g0), gloss, token_ptr = ctx.folded
+            dfeat_s = torch.empty_like(dfeat0)
+            gl = gloss.detach().float().reshape(1)
+            L.launch("sr_scale_by", L.lib().sr_scale_by, dfeat_s.data_ptr(), dfeat0.data_ptr(), dfeat0.numel(), gl.data_ptr(),
+                     L.DTYPE_CODE[dfeat0.dtype], L.stream_ptr(dfeat0.device))
+            folded = (dfeat_s, g0 * gloss)
+            if dout.data_ptr() == token_ptr and all(st_ == 0 for st_ in dout.stride()):
+                return _TailFunction._split(ctx, *folded)
+        dout = dout.contiguous().float()
+        if feat.dtype == torch.bfloat16:
+            dfeat, g = HP.tail_bwd(dout, feat, x, blob, ctx.mean, ctx.r)
+        else:
+            dfeat = torch.empty_like(feat)
+            HP.tail_bwd_data(dout, dfeat, blob, ctx.r)
+            g = HP.tail_wgrad(dout, feat, x, ctx.mean, ctx.r)
+        if folded is not None:
+            dfeat, g = dfeat + folded[0], g + folded[1]
+        return _TailFunction._split(ctx, dfeat, g)
 
 
 def _body_kinds(f: int):

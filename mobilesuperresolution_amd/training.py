@@ -10,7 +10,7 @@ and then, as before (pretrain.py:69-82):
     optimizer.zero_grad(); sr = model(lr); loss = w * criterions['l1'](sr, hr); loss.backward(); optimizer.step(); loss.item()
 
 What changes underneath.  `criterion(sr, hr)` recognises an `sr` that came straight out of BASIC_MODEL.forward (its grad_fn is
-the network's autograd node) and runs the network's backward right there with the loss folded into the tail-backward kernel
+the network's autograd node; likewise NAS_MODEL's `sr, speed = model(lr)`, search.py:74: there the tail's node) and runs the network's backward right there with the loss folded into the tail-backward kernel
 (csrc/wdsr_ends.h, sr_tail_bwd_loss): no d(loss)/d(sr) tensor, none of the seven small ATen loss kernels; `loss.backward()` then
 only hands the finished parameter gradient over (scaled by whatever the trainer multiplied the loss with).  `Adam.step()` is ONE
 launch of the library's Adam kernel per parameter tensor (BASIC_MODEL has one flat parameter) with torch.optim.Adam's
@@ -30,48 +30,78 @@ from . import _lib as L
 __all__ = ["L1Loss", "L1_Charbonnier_loss", "Adam"]
 
 
+class _BasicFold:
+    """BASIC_MODEL: the node is the whole network's; folding runs the network's backward, the payload is the flat gradient"""
+
+    @staticmethod
+    def can_fold(node, sr, hr):
+        return node.model._can_fold(node, sr, hr)
+
+    @staticmethod
+    def run(node, sr, hr, kind):
+        model = node.model
+        gflat, _keep = model._backward_folded(node, sr, hr, kind)
+        st = model._state(sr.device)
+        return gflat, st.loss_part
+
+
+class _NodeFold:
+    """NAS_MODEL: the node is the tail's (models/wdsr_b.py:_TailFunction); folding runs the tail's backward, the body's runs
+    later under autograd"""
+
+    @staticmethod
+    def can_fold(node, sr, hr):
+        return node.can_fold(node, sr, hr)
+
+    @staticmethod
+    def run(node, sr, hr, kind):
+        return node.fold_loss(node, sr, hr, kind)
+
+
 def _network_node(sr: torch.Tensor):
-    """the BASIC_MODEL autograd node that produced `sr`, or None"""
+    """(autograd node that produced `sr`, its folding adapter) if it is one of this package's output nodes, else (None, None)"""
     fn = sr.grad_fn
-    if fn is None or type(fn).__name__ != "_NetFunctionBackward" or not hasattr(fn, "model"):
-        return None
-    return fn
+    if fn is None:
+        return None, None
+    name = type(fn).__name__
+    if name == "_NetFunctionBackward" and hasattr(fn, "model"):
+        return fn, _BasicFold
+    if name == "_TailFunctionBackward" and hasattr(fn, "fold_loss"):
+        return fn, _NodeFold
+    return None, None
 
 
 class _FoldedCriterion(torch.autograd.Function):
-    """loss(sr, hr) where sr = BASIC_MODEL(x): forward() runs the network's BACKWARD with the loss gradient formed inside the
-    tail-backward kernel and returns the loss value; backward() parks the parameter gradient on the network's node and sends a
+    """loss(sr, hr) where sr = BASIC_MODEL(x) or NAS_MODEL(x)[0]: forward() runs the BACKWARD of sr's node with the loss gradient
+    formed inside the tail-backward kernel and returns the loss value; backward() parks the result on the node and sends a
     zero-stride zero token up the graph in place of d(loss)/d(sr)."""
 
     @staticmethod
-    def forward(ctx, sr, hr, node, kind):
-        model = node.model
-        gflat, keep = model._backward_folded(node, sr, hr, kind)
-        st = model._state(sr.device)
+    def forward(ctx, sr, hr, node, fold, kind):
+        payload, loss_part = fold.run(node, sr, hr, kind)
         loss = torch.empty((), dtype=torch.float32, device=sr.device)
         with torch.cuda.device(sr.device):
-            L.launch("sr_loss_value", L.lib().sr_loss_value, st.loss_part.data_ptr(), st.wgs_tail, 1.0 / sr.numel(), loss.data_ptr(),
+            L.launch("sr_loss_value", L.lib().sr_loss_value, loss_part.data_ptr(), loss_part.numel(), 1.0 / sr.numel(), loss.data_ptr(),
                      L.stream_ptr(sr.device))
         ctx.node = node
         ctx.token = torch.zeros(1, dtype=sr.dtype, device=sr.device).expand(sr.shape)
-        ctx.save_for_backward(gflat)
+        ctx.payload = payload
         return loss
 
     @staticmethod
     def backward(ctx, gloss):
-        (gflat,) = ctx.saved_tensors
-        ctx.node.folded = (gflat, gloss, ctx.token.data_ptr())
-        return ctx.token, None, None, None
+        ctx.node.folded = (ctx.payload, gloss, ctx.token.data_ptr())
+        return ctx.token, None, None, None, None
 
 
 class _HotLoss(nn.Module):
     KIND = "l1"
 
     def forward(self, sr: torch.Tensor, hr: torch.Tensor) -> torch.Tensor:
-        node = _network_node(sr) if (torch.is_grad_enabled() and sr.requires_grad) else None
-        if node is None or getattr(node, "folded", None) is not None or not node.model._can_fold(node, sr, hr):
+        node, fold = _network_node(sr) if (torch.is_grad_enabled() and sr.requires_grad) else (None, None)
+        if node is None or getattr(node, "folded", None) is not None or not fold.can_fold(node, sr, hr):
             return self._torch_loss(sr, hr)
-        return _FoldedCriterion.apply(sr, hr.detach().contiguous().float(), node, self.KIND)
+        return _FoldedCriterion.apply(sr, hr.detach().contiguous().float(), node, fold, self.KIND)
 
 
 class L1Loss(_HotLoss):

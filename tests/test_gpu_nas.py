@@ -307,3 +307,44 @@ def test_nas_fused_block_backward_matches_separate_kernels(monkeypatch, units):
         else:
             scale = max(float(gb[k].abs().max()), 1e-12)
             assert float((ga[k] - gb[k]).abs().max()) <= 2e-5 * scale, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,weight", [("bf16", 1.0), ("bf16", 0.37), ("fp32", 0.37)])
+def test_nas_search_loop_with_the_drop_in_criterion(dtype, weight):
+    """search.py:72-89 unchanged -- `loss = w * criterions['l1'](sr, hr) + speed term; loss.backward()` -- with
+    mobilesuperresolution_amd.training.L1Loss in place of nn.L1Loss: the loss is folded into the tail-backward kernel (no
+    d(loss)/d(sr) tensor).  Same loss value and the same gradients as with nn.L1Loss on the same model: exactly for w = 1 in the
+    fp32 parameters' gradients of the tail (same fp32 products), within bf16 rounding elsewhere (the data gradient is
+    rounded to bf16 before the weight is applied instead of after)"""
+    from mobilesuperresolution_amd.models import get_model
+    from mobilesuperresolution_amd.training import L1Loss
+    torch.manual_seed(4)
+    m = get_model(_nas_ns(num_residual_units=24, hot_dtype=dtype)).cuda().train()
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(2, 3, 24, 40, generator=g).cuda()
+    hr = torch.rand(2, 3, 96, 160, generator=g).cuda()
+    res = []
+    for crit in (torch.nn.L1Loss(), L1Loss()):
+        m.zero_grad(set_to_none=True)
+        sr, speed = m(x)
+        loss = weight * crit(sr, hr) + 0.1 * speed.sum()
+        loss.backward()
+        res.append((loss.detach().clone(), {k: (None if t is None else t.clone()) for k, t in m.named_reference_tensors(grads=True)}))
+    (l0, g0), (l1, g1) = res
+    assert abs(l1.item() - l0.item()) <= 1e-6 * abs(l0.item()) + 1e-7, (l0.item(), l1.item())
+    tol = 2e-6 if dtype == "fp32" else (1e-6 if weight == 1.0 else 1e-2)
+    worst = 0.0
+    for k in g0:
+        a, b = g0[k], g1[k]
+        if a is None or float(a.abs().max()) == 0.0:
+            assert b is None or float(b.abs().max()) <= 1e-7, k
+            continue
+        e = ((b - a).norm() / a.norm()).item()
+        worst = max(worst, e)
+        assert e <= tol, (k, e)
+    print(f"\nNAS drop-in criterion ({dtype}, w = {weight}): worst per-tensor grad rel L2 {worst:.2e}")
+    # a criterion on something else than the model's own output takes torch's ops
+    sr, speed = m(x)
+    other = L1Loss()(sr[:, :, ::2], hr[:, :, ::2])
+    assert torch.allclose(other, torch.nn.functional.l1_loss(sr[:, :, ::2], hr[:, :, ::2]))

@@ -11,10 +11,12 @@ m = get_model(ns).to(dev).train()
 opt = torch.optim.Adam(m.parameters(), lr=1e-3, fused=True)
 x = torch.rand(32, 3, 48, 48, device=dev)
 hr = torch.rand(32, 3, 192, 192, device=dev)
+from mobilesuperresolution_amd.training import L1Loss
+crit = torch.nn.L1Loss() if os.environ.get("NAS_TORCH_LOSS") else L1Loss()      # search.py:261 criterions['l1']
 def step():
     opt.zero_grad(set_to_none=True)
     out, speed = m(x)
-    (torch.nn.functional.l1_loss(out, hr) + 0.1 * speed.sum()).backward()
+    (1.0 * crit(out, hr) + 0.1 * speed.sum()).backward()                       # search.py:74-89
     opt.step()
 for _ in range(3):
     step()
