@@ -12,7 +12,9 @@
 
 struct C3Cfg {
   static constexpr int CO = 24, COC = 3;                        // output channels / 8-channel chunks
-  static constexpr int TH = 12, TW = 24, HW = TW + 2, HH = TH + 2, NPXH = HW * HH, NPXH_PAD = (NPXH + 31) / 32 * 32;
+  // 16 x 16 tiles: a 64 x 64 frame is 16 tiles, so a BasicVSR frame step of 8 clips x 2 directions is 256 workgroups = ONE round
+  // on 256 CUs (12 x 24 tiles made it 288: a second round for 32 of them)
+  static constexpr int TH = 16, TW = 16, HW = TW + 2, HH = TH + 2, NPXH = HW * HH, NPXH_PAD = (NPXH + 31) / 32 * 32;
   static constexpr int NPT_O = (TH / 4) * (TW / 8), NPXC = TH * TW;
   static constexpr int KSF = 18;                                // forward k-steps: 9 taps x 4 chunks of the 32-wide row
   static constexpr int KSB = 14;                                // backward-data k-steps: 9 offsets x 3 chunks of dz
@@ -372,15 +374,15 @@ __global__ __launch_bounds__((64 * 9)) void c3_wgrad_kernel(const T* __restrict_
 }
 
 // =============================================================================================
-// One ResidualBlockNoBN per launch (bf16): a per-layer launch on a 64x64 clip batch is 144 workgroups of <1 us
+// One ResidualBlockNoBN per launch (bf16): a per-layer launch on a 64x64 clip batch is 128 workgroups of <1 us
 // of work under a ~5 us launch floor, so the two convs of a block share a launch.  conv1 + ReLU runs on the
 // tile + 1-pixel halo from x on a 2-pixel halo and hands t to conv2 through LDS; t is still written once (core)
 // because backward needs it.  Bit-identical to c3_fwd<ReLU> followed by c3_fwd<none, +res>.
 // =============================================================================================
 struct C3Pair {
   typedef C3Cfg C;
-  static constexpr int W2 = C::TW + 4, H2 = C::TH + 4, NP2 = W2 * H2;       // 28 x 16 = 448
-  static constexpr int NPT_H = C::NPXH_PAD / 32;                             // 12 pixel tiles over the 14x26 region
+  static constexpr int W2 = C::TW + 4, H2 = C::TH + 4, NP2 = W2 * H2;       // 20 x 20 = 400
+  static constexpr int NPT_H = C::NPXH_PAD / 32;                             // 11 pixel tiles over the 18x18 region
   static constexpr int X2_ELEMS = (NP2 + 2) * 32, T1_ELEMS = (C::NPXH_PAD + 2) * 32;
   static constexpr int G2_ELEMS = (NP2 + 2) * C::CO, M1_ELEMS = (C::NPXH_PAD + 2) * C::CO;
 };
@@ -443,7 +445,7 @@ __global__ __launch_bounds__((64 * C3Pair::NPT_H)) void c3_resblock_fwd_kernel(c
   }
   __syncthreads();
 
-  // ---- conv1 + ReLU on the 14x26 region ----
+  // ---- conv1 + ReLU on the tile + 1-pixel halo ----
   {
     const int hp1 = wave * 32 + r;
     const bool live = hp1 < C::NPXH;
@@ -539,7 +541,7 @@ __global__ __launch_bounds__((64 * C3Pair::NPT_H)) void c3_resblock_bwd_data_ker
   }
   __syncthreads();
 
-  // ---- gt = conv2^T(g) on the 14x26 region; DZ = gt * relu'(t) ----
+  // ---- gt = conv2^T(g) on the tile + 1-pixel halo; DZ = gt * relu'(t) ----
   {
     const int hp1 = wave * 32 + r;
     const bool live = hp1 < C::NPXH;

@@ -254,10 +254,14 @@ def forward_warped_pair(trunk_a, trunk_b, frames, state=None, flow=None, flow_bo
     return feat, new_state
 
 
-def _wgrad_wgs(n, h, w, cap=72):
-    """workgroups per conv for the weight-gradient launches: every workgroup walks the same number of 12x24 tiles (144 tiles
-    at C4 -> 72 workgroups x 2 tiles; 64 workgroups left a quarter of them idle in the third round)"""
-    total = n * ((h + 11) // 12) * ((w + 23) // 24)
+_TILE = 16                                             # csrc/conv3x3.h C3Cfg::TH = TW
+
+
+def _wgrad_wgs(n, h, w, cap=None):
+    """workgroups per conv for the weight-gradient launches: every workgroup walks the same number of 16x16 tiles (256 tiles
+    at C4 with both directions in one launch -> 64 workgroups x 4 tiles; 128 and 256 workgroups measured slower: more slabs to reduce)"""
+    cap = int(os.environ.get("SR_C3_WGRAD_WGS", 64)) if cap is None else cap
+    total = n * ((h + _TILE - 1) // _TILE) * ((w + _TILE - 1) // _TILE)
     per = -(-total // cap)
     return -(-total // per)
 
@@ -403,7 +407,7 @@ class _TrunkWarpFunction(torch.autograd.Function):
         dev = acts.device
         need_frame, need_state, need_flow = ctx.need
         n_dir, bstride, mod2 = ctx.n_dir, ctx.bstride, ctx.mod2
-        wgs = _wgrad_wgs(n, h, w) if not n_dir else 2 * _wgrad_wgs(n_dir, h, w)
+        wgs = _wgrad_wgs(n, h, w) if not n_dir else 2 * _wgrad_wgs(n_dir, h, w, int(os.environ.get("SR_C3_WGRAD_WGS", 64)) // 2)
         with torch.cuda.device(dev):
             _, _, boff, _ = _trunk_tables(27, nb, dev.index)
             s0, d0, s1, d1 = _unpack_tables(27, dev.index)
