@@ -242,16 +242,17 @@ def forward_warped_pair(trunk_a, trunk_b, frames, state=None, flow=None, flow_bo
     """ONE recurrent step of BOTH propagation directions (reference: the two loops of basicvsr_arch.py:67-88, which are
     independent of each other): frames (2N, 3, H, W) = [the backward-time loop's frame | the forward-time loop's frame], state / flow
     likewise (2N, ...); the first half runs through `trunk_a`, the second through `trunk_b`, in the same launches -- twice the
-    workgroups per launch and half the dependent launches of two forward_warped calls.  Returns (features (2N, F, H, W), state)."""
+    workgroups per launch and half the dependent launches of two forward_warped calls.  Returns (trunk_a's features (N, F, H, W),
+    trunk_b's features (N, F, H, W), state (2N, ...))."""
     if flow is not None and flow_bound is None:
         flow_bound = flow.detach().abs().amax()
-    feat, new_state = _TrunkWarpFunction.apply(frames, state, flow, flow_bound, trunk_a, trunk_a.flat, trunk_b, trunk_b.flat)
+    feat_a, feat_b, new_state = _TrunkWarpFunction.apply(frames, state, flow, flow_bound, trunk_a, trunk_a.flat, trunk_b, trunk_b.flat)
     half = frames.shape[0] // 2
-    for tr, sl in ((trunk_a, slice(0, half)), (trunk_b, slice(half, None))):
+    for tr, sl, ft in ((trunk_a, slice(0, half), feat_a), (trunk_b, slice(half, None), feat_b)):
         for hook in tr._forward_hooks.values():       # forward hooks of the two modules see their half of the step, as with forward_warped
             hook(tr, (frames[sl], None if state is None else state[sl], None if flow is None else flow[sl], flow_bound),
-                 (feat[sl], new_state[sl]))
-    return feat, new_state
+                 (ft, new_state[sl]))
+    return feat_a, feat_b, new_state
 
 
 _TILE = 16                                             # csrc/conv3x3.h C3Cfg::TH = TW
@@ -395,11 +396,21 @@ class _TrunkWarpFunction(torch.autograd.Function):
         ctx.frame, ctx.state, ctx.flow, ctx.bound = frame_, state_, flow_, bound_
         ctx.need = (frame.requires_grad, state is not None and state.requires_grad, flow is not None and flow.requires_grad)
         ctx.set_materialize_grads(False)
+        if mod2 is not None:
+            # the two trunks' features as two outputs: slicing one output outside would cost autograd a fill, a copy and an add per
+            # half and step on the way back
+            return out[:n_dir], out[n_dir:], acts[nb]
         return out, acts[nb]
 
     @staticmethod
-    def backward(ctx, dy, dnext):
+    def backward(ctx, *grads):
         import ctypes
+        if ctx.mod2 is not None:
+            dya, dyb, dnext = grads
+            dy = None
+        else:
+            dy, dnext = grads
+            dya = dyb = None
         mod, acts, mids, blob = ctx.mod, ctx.acts, ctx.mids, ctx.blob
         frame, state, flow, bound = ctx.frame, ctx.state, ctx.flow, ctx.bound
         dt, nb, nf = mod.hot_dtype, mod.num_block, mod.num_feat
@@ -414,7 +425,25 @@ class _TrunkWarpFunction(torch.autograd.Function):
             ga = torch.empty_like(acts)
             gt = torch.empty_like(mids)
             tgt = ga[nb]
-            if dy is not None:
+            if ctx.mod2 is not None:                      # per half: its feature gradient (or none) plus the state's
+                for sl, d in ((slice(0, n_dir), dya), (slice(n_dir, None), dyb)):
+                    t_, dn = tgt[sl], (dnext[sl] if dnext is not None else None)
+                    if d is not None:
+                        src = d.permute(0, 2, 3, 1)
+                        if nf < 24:
+                            t_.zero_()
+                            t_[..., :nf] = src
+                            if dn is not None:
+                                t_.add_(dn)
+                        elif dn is not None:
+                            torch.add(src, dn, out=t_)
+                        else:
+                            t_.copy_(src)
+                    elif dn is not None:
+                        t_.copy_(dn)
+                    else:
+                        t_.zero_()
+            elif dy is not None:
                 src = dy.permute(0, 2, 3, 1)
                 if nf < 24:
                     tgt.zero_()
@@ -493,9 +522,9 @@ def propagate(x, flows_forward, flows_backward, backward_trunk, forward_trunk, f
             fl = torch.cat([flows_backward.flip(1), flows_forward], 0) if n > 1 else None
             state = None
             for k in range(n):
-                feat, state = forward_warped_pair(backward_trunk, forward_trunk, xp[:, k], state, fl[:, k - 1] if k > 0 else None, bound)
-                out_b.insert(0, feat[:b])
-                out_f.append(feat[b:])
+                fb, ff, state = forward_warped_pair(backward_trunk, forward_trunk, xp[:, k], state, fl[:, k - 1] if k > 0 else None, bound)
+                out_b.insert(0, fb)
+                out_f.append(ff)
             return out_b, out_f
         cur = torch.cuda.current_stream(x.device)
         side = _side_stream(x.device) if os.environ.get("SR_VSR_TWO_STREAMS", "0") == "1" else cur
