@@ -96,11 +96,23 @@ static int launch_fwd_rs(const void* x, void* ya, void* yb, const void* wa, cons
     // whole 48-wide images, at least one per CU and the last round of workgroups reasonably full: the streaming kernel
     // (csrc/wdsr_fwd_stream.h: no halo recompute, one barrier per band), with or without the saved t images
     if (fwd_stream_applies(N, H, W)) {
-      if (tsa && tsb)
-        hipLaunchKernelGGL((wdsr_fwd_stream_kernel<F, E, L, true>), dim3(256), dim3(512), 0, st, (const T*)x, (T*)ya, (T*)yb, (const T*)wa,
+#ifdef SR_FORCE_STREAM8                                 // (tools/build_variant.sh: A/B timing of the eight-wave form)
+      static const bool eight = true;
+#else
+      static const bool eight = SR_AB("SR_STREAM8");   // (diagnostic build: the eight-wave form, one block's whole weight set per wave)
+#endif
+      if (eight) {
+        if (tsa && tsb)
+          hipLaunchKernelGGL((wdsr_fwd_stream_kernel<F, E, L, true>), dim3(256), dim3(512), 0, st, (const T*)x, (T*)ya, (T*)yb, (const T*)wa,
+                             (const T*)wb, cia, cib, (T*)tsa, (T*)tsb, N, H);
+        else
+          hipLaunchKernelGGL((wdsr_fwd_stream_kernel<F, E, L, false>), dim3(256), dim3(512), 0, st, (const T*)x, (T*)ya, (T*)yb, (const T*)wa,
+                             (const T*)wb, cia, cib, (T*)nullptr, (T*)nullptr, N, H);
+      } else if (tsa && tsb)
+        hipLaunchKernelGGL((wdsr_fwd_stream12_kernel<F, E, L, true>), dim3(256), dim3(768), 0, st, (const T*)x, (T*)ya, (T*)yb, (const T*)wa,
                            (const T*)wb, cia, cib, (T*)tsa, (T*)tsb, N, H);
       else
-        hipLaunchKernelGGL((wdsr_fwd_stream_kernel<F, E, L, false>), dim3(256), dim3(512), 0, st, (const T*)x, (T*)ya, (T*)yb, (const T*)wa,
+        hipLaunchKernelGGL((wdsr_fwd_stream12_kernel<F, E, L, false>), dim3(256), dim3(768), 0, st, (const T*)x, (T*)ya, (T*)yb, (const T*)wa,
                            (const T*)wb, cia, cib, (T*)nullptr, (T*)nullptr, N, H);
       SR_HIP_CHECK_LAUNCH();
       return 0;

@@ -80,7 +80,7 @@ template <typename C, int TWP> struct StBAddr {
 // conv1 -> ReLU -> conv2 of one band: Xin = the band's 192 pixel rows (24 channels each), t -> ring rows (y & 15), padded column
 // c + 1; SAVE_T: also into the weight-gradient kernels' tile-local image [tile 12 x 24][288][LP] of this image.  Wave gw of the
 // group takes pixel tiles gw and gw + 4.
-template <typename S, bool SAVE_T>
+template <typename S, bool SAVE_T, int NWR = 4>
 SR_DEV void st_phase_a(const __bf16* Xin, const __bf16* ones, __bf16* Tring, const RwA<typename S::C>& w, const float* cl,
                        __bf16* tsave_img, int row0, int band, int H, int gw, int lane) {
   typedef typename S::C C;
@@ -89,10 +89,10 @@ SR_DEV void st_phase_a(const __bf16* Xin, const __bf16* ones, __bf16* Tring, con
   int tile = gw;
   rw_x_frags<C, S::KXL>(xb, Xin, ones, tile * 32 + r, hh);
 #pragma unroll 1
-  for (; tile < S::NTB; tile += 4) {
+  for (; tile < S::NTB; tile += NWR) {
     const f32x16 t = rw_t_tile<C>(xb, w, cl, hh, [](int) {});
     const int p = tile * 32 + r;
-    if (tile + 4 < S::NTB) rw_x_frags<C, S::KXL>(xb, Xin, ones, p + 128, hh);      // the next tile's operands land under the stores
+    if (tile + NWR < S::NTB) rw_x_frags<C, S::KXL>(xb, Xin, ones, p + 32 * NWR, hh);      // the next tile's operands land under the stores
     const int row = p / S::W, c = p - row * S::W, y = band * S::BR + row;
     RwPix px;
     px.hp = ((row0 + y) & 15) * S::TWP + c + 1;
@@ -109,7 +109,7 @@ SR_DEV void st_phase_a(const __bf16* Xin, const __bf16* ones, __bf16* Tring, con
 // 3x3 conv + bias + residual of one band: t from the ring, the residual from Xres (the band's 192 pixel rows of the block
 // input), y -> Ynext (the band's rows of the next block's input ring; nullptr = none) and -> the global image yout (nullptr =
 // none).  Wave gw takes pixel tiles 3 - gw and 7 - gw: the waves with ONE conv1/conv2 tile per band take two 3x3 tiles.
-template <typename S>
+template <typename S, int NWR = 4>
 SR_DEV void st_phase_b(const __bf16* Tring, const __bf16* Xres, const __bf16* ones, const __bf16* zrow, __bf16* Ynext, __bf16* yout,
                        const RwB<typename S::C>& w, int row0, int band, int H, int gw, int lane) {
   typedef typename S::C C;
@@ -118,7 +118,7 @@ SR_DEV void st_phase_b(const __bf16* Tring, const __bf16* Xres, const __bf16* on
   const bool to_global = yout != nullptr;
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yout, 0, to_global ? H * S::W * C::F * 2 : 0, 0x00020000);
 #pragma unroll 1
-  for (int tile = 3 - gw; tile < S::NTB; tile += 4) {
+  for (int tile = NWR - 1 - gw; tile < S::NTB; tile += NWR) {
     const int p = tile * 32 + r;
     const int row = p / S::W, c = p - row * S::W, y = band * S::BR + row;
     A a;
@@ -258,6 +258,19 @@ template <typename S, bool SAVE_T> struct StPipe {
   }
   template <int K> SR_DEV void epi(const f32x16& r, const Job<K>& j) const {
     if constexpr (K == ST_JA) a_epi(r, j); else b_epi(r, j);
+  }
+  template <int K0, int K1> SR_DEV void run2(int t0, int t1, const RwA<C>& wa, const RwB<C>& wb) const {
+    Job<K0> j0;
+    addr<K0>(j0, t0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) read<K0>(j0, i);
+    Job<K1> j1;
+    addr<K1>(j1, t1);
+    const f32x16 r0 = body<K0>(j0, wa, wb, [&](int st) { hook_reads<K0, K1>(j1, st); });
+    epi<K0>(r0, j0);
+    rest_reads<K0, K1>(j1);
+    const f32x16 r1 = body<K1>(j1, wa, wb, [](int) {});
+    epi<K1>(r1, j1);
   }
   template <int K0, int K1, int K2> SR_DEV void run3(int t0, int t1, int t2, const RwA<C>& wa, const RwB<C>& wb) const {
     Job<K0> j0;
@@ -434,5 +447,175 @@ __global__ __launch_bounds__(512) void wdsr_fwd_stream_kernel(const __bf16* __re
     if (i == 8) SR_STAMP_AT(5);
     if (i == 0) SR_STAMP_AT(6);
     if (i == GB + 4) SR_STAMP_AT(7);
+  }
+}
+
+
+// =============================================================================================
+// TWELVE waves, one ROLE per wave (round 3, second form).  The eight-wave kernel above gives every wave one block's whole
+// weight set (124 VGPRs) and two waves per SIMD; its counters say the matrix pipe and the vector pipe are busy one AFTER the
+// other (MFMA busy 40-48 %, VALU the rest): two waves do not cover each other's dependent chains.  Here a wave holds the
+// weights of ONE phase only -- waves 0-2: conv1/conv2 of block 0 (76 VGPRs), 3-5: its 3x3 (48), 6-8: conv1/conv2 of block 1,
+// 9-11: its 3x3 -- which fits three waves per SIMD (168 VGPRs each).  A role's three waves take two of the band's six pixel
+// tiles each, pipelined as two jobs; the four roles of a round run side by side with the same lags (A0: band i, B0: i - 2,
+// A1: i - 3, B1: i - 5) and the same single barrier.  Same per-pixel arithmetic: bit-identical.
+// =============================================================================================
+template <int F, int E, int L, bool SAVE_T>
+__global__ __launch_bounds__(768) void wdsr_fwd_stream12_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ ya,
+                                                                __bf16* __restrict__ yb, const __bf16* __restrict__ wa,
+                                                                const __bf16* __restrict__ wb, const float* __restrict__ cia,
+                                                                const float* __restrict__ cib, __bf16* __restrict__ tsa,
+                                                                __bf16* __restrict__ tsb, int N, int H) {
+  typedef StreamCfg<F, E, L> S;
+  typedef typename S::C C;
+  typedef typename S::R R;
+  constexpr int NW = 12, NWR = 3, NTHREADS = 64 * NW;
+  static_assert(S::NTB == 2 * NWR, "two pixel tiles of a band per wave of a role");
+  __shared__ __attribute__((aligned(16))) char smem_raw[S::LDS_BYTES];
+  __bf16* const XR = reinterpret_cast<__bf16*>(smem_raw);
+  __bf16* const T0 = XR + S::X_ELEMS;
+  __bf16* const Y0 = T0 + S::T_ELEMS;
+  __bf16* const T1 = Y0 + S::X_ELEMS;
+  __bf16* const ONES = T1 + S::T_ELEMS;
+  __bf16* const ZROW = ONES + 8;
+  float* const CL = reinterpret_cast<float*>(ONES + S::ONES_ELEMS);
+  __bf16* const PARK = T0;                                             // prologue only: both blocks' weight fragments
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave / NWR, gw = wave - role * NWR;                 // 0: A0, 1: B0, 2: A1, 3: B1
+  const int blk = role >> 1;
+  const bool is_b = role & 1;
+  const int NB = H / S::BR;
+  const int K = ((int)blockIdx.x < N) ? (N - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;   // this workgroup's images
+  const int GB = K * NB;                                               // its bands
+  const size_t img_elems = (size_t)H * S::W * F;
+  const int tiles_img = ((H + C::TH - 1) / C::TH) * (S::W / C::TW);
+  const char* zeros = reinterpret_cast<const char*>(g_sr_const_chunks) + 16;
+  auto image_of = [&](int g, int& b) {                  // global band g -> image index, band in the image
+    const int k = g / NB;
+    b = g - k * NB;
+    return (int)blockIdx.x + k * (int)gridDim.x;
+  };
+  auto stage_x = [&](int g) {                           // a band's rows are ONE contiguous 9 KB run of its image: waves 0 .. 8 one piece each
+    if (wave < S::XPIECES) {
+      int b;
+      const int n = image_of(g, b);
+      const char* src = reinterpret_cast<const char*>(x + (size_t)n * img_elems) + (size_t)b * (S::BPX * S::KXL * 2);
+      const unsigned dst = lds_addr(XR) + (g & 3) * (S::BPX * S::KXL * 2);
+      dma_piece16(src + wave * 1024 + lane * 16, dst + wave * 1024);
+    }
+  };
+  static_assert(S::XPIECES <= NW, "one x piece per wave");
+
+  // ---- prologue: as in the eight-wave kernel ----
+  if (GB > 0) stage_x(0);
+#pragma unroll 1
+  for (int p = R::P_C + wave; p < R::P_END; p += NW) {
+    if (p < R::P_W) {
+      const int k = p - R::P_C, b_ = k / (R::CL_FLOATS / 64), i = (k % (R::CL_FLOATS / 64)) * 64 + lane;
+      const float* tab = b_ == 1 ? cib : cia;
+      const char* src = i < C::CINIT_FWD ? reinterpret_cast<const char*>(tab + i) : zeros + (lane & 3) * 4;
+      dma_piece4(src, lds_addr(CL) + k * 256);
+    } else {
+      const int fr = p - R::P_W;
+      const __bf16* wsrc = fr >= R::NFR ? wb + (size_t)R::src_frag(fr - R::NFR) * 512 : wa + (size_t)R::src_frag(fr) * 512;
+      dma_piece16(reinterpret_cast<const char*>(wsrc + lane * 8), lds_addr(PARK) + fr * 1024);
+    }
+  }
+  if (tid < S::ONES_ELEMS) ONES[tid] = tid == 0 ? (__bf16)1.f : (__bf16)0.f;
+  wait_vmcnt<0>();
+  __syncthreads();
+
+  const float* const cl = CL + blk * R::CL_FLOATS;
+  constexpr int BAND_ELEMS = S::BPX * S::KXL;
+  __bf16* const ts = blk ? tsb : tsa;
+  __bf16* const Tr = blk ? T1 : T0;
+  __bf16* const In = blk ? Y0 : XR;                     // this block's input ring
+
+  // after the weights are in registers: the parking area is freed, the rings zeroed (and the saved images' padding rows)
+  auto after_weights = [&]() {
+    __syncthreads();
+    {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      u32x4* t0 = reinterpret_cast<u32x4*>(T0);
+      u32x4* t1 = reinterpret_cast<u32x4*>(T1);
+      for (int i = tid; i < S::T_ELEMS * 2 / 16; i += NTHREADS) { t0[i] = z; t1[i] = z; }
+    }
+    if constexpr (SAVE_T) {
+      if (!is_b) {                                      // the conv1/conv2 waves of a block: its saved image's rows below the picture
+        const int rows_pad = ((H + C::TH - 1) / C::TH) * C::TH - H;
+        constexpr int PPX = C::LP * 2 / 16;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int k = 0; k < K; ++k) {
+          __bf16* const ts_img = ts + (size_t)((int)blockIdx.x + k * (int)gridDim.x) * tiles_img * (C::TH * C::TW) * C::LP;
+          for (int i = gw * 64 + lane; i < rows_pad * S::W * PPX; i += 64 * NWR) {
+            const int px = i / PPX, q = i - px * PPX;
+            const int y = H + px / S::W, c = px % S::W;
+            const int ty = y / C::TH, tx = c / C::TW;
+            const int off = (((ty * (S::W / C::TW) + tx) * (C::TH * C::TW)) + (y - ty * C::TH) * C::TW + (c - tx * C::TW)) * C::LP + q * 8;
+            stream_store(reinterpret_cast<u32x4*>(ts_img + off), z);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  };
+  // end of a round: this wave's x piece of the next band has landed (vmcnt retires in issue order: the piece was issued before
+  // the round's `nst` global stores, which stay in flight), then the barrier
+  auto end_round = [&](int nst) {
+    if (nst >= 6) wait_vmcnt<6>();
+    else wait_vmcnt<0>();
+    __syncthreads();
+  };
+
+  if (!is_b) {
+    RwA<C> rwa;
+    RwB<C> none;                                         // (never read)
+    rwa.load(PARK + blk * R::W_ELEMS, lane);
+    after_weights();
+    const int lag = blk ? 3 : 0;
+#pragma unroll 1
+    for (int i = 0; i < GB + 5; ++i) {
+      if (i + 1 < GB) stage_x(i + 1);
+      const int ga = i - lag;
+      const bool has = ga >= 0 && ga < GB;
+      if (has) {
+        int ba = 0;
+        const int na = image_of(ga, ba);
+        const __bf16* const a_in = In + (ga & 3) * BAND_ELEMS;
+        __bf16* const a_ts = SAVE_T ? ts + (size_t)na * tiles_img * (C::TH * C::TW) * C::LP : nullptr;
+        StPipe<S, SAVE_T> pp;
+        pp.ones = ONES; pp.zrow = ZROW; pp.H = H; pp.lane = lane;
+        pp.ca = {a_in, Tr, cl, a_ts, (ga - ba) * S::BR, ba};
+        pp.template run2<ST_JA, ST_JA>(gw, gw + NWR, rwa, none);
+      }
+      end_round((SAVE_T && has) ? 6 : 0);
+    }
+  } else {
+    RwA<C> none;
+    RwB<C> rwb;
+    rwb.load(PARK + blk * R::W_ELEMS, lane);
+    after_weights();
+    const int lag = blk ? 5 : 2;
+#pragma unroll 1
+    for (int i = 0; i < GB + 5; ++i) {
+      if (i + 1 < GB) stage_x(i + 1);
+      const int gb = i - lag;
+      const bool has = gb >= 0 && gb < GB;
+      bool stores = false;
+      if (has) {
+        int bb = 0;
+        const int nb = image_of(gb, bb);
+        const __bf16* const b_res = In + (gb & 3) * BAND_ELEMS;
+        __bf16* const b_next = blk ? nullptr : Y0 + (gb & 3) * BAND_ELEMS;
+        __bf16* const b_out = blk ? yb + (size_t)nb * img_elems : (ya ? ya + (size_t)nb * img_elems : nullptr);
+        stores = b_out != nullptr;
+        StPipe<S, SAVE_T> pp;
+        pp.ones = ONES; pp.zrow = ZROW; pp.H = H; pp.lane = lane;
+        pp.cb = {Tr, b_res, b_next, b_out, (gb - bb) * S::BR, bb};
+        pp.template run2<ST_JB, ST_JB>(gw, gw + NWR, none, rwb);
+      }
+      end_round(stores ? 6 : 0);
+    }
   }
 }
