@@ -432,11 +432,11 @@ def main():
             alg5 = units * algorithmic_bytes(big, LR, LR, UNITS, BLOCKS, SCALE, s)["sr_wdsr_block_fwd"]
             # one whole image per workgroup: the streaming kernel (csrc/wdsr_fwd_stream.h), 4 464 MFMAs per image and two blocks
             floor5 = 4464 * (big / 256) / 4 * 32 / 2.4e3
-            roofline["batch512"] = {"kernel": "wdsr_fwd_stream_kernel<24,144,20,false>", "avg_launch_us": round(us5, 2),
+            roofline["batch512"] = {"kernel": "wdsr_fwd_stream12_kernel<24,144,20,false>", "avg_launch_us": round(us5, 2),
                                     "achieved": round(alg5 / (us5 * 1e-6) / 1e9, 1),
                                     "frac": round(alg5 / (us5 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "mfma_floor_us": round(floor5, 2),
                                     "mfma_frac": round(floor5 / us5, 4),
-                                    "training_variant": {"kernel": "wdsr_fwd_stream_kernel<24,144,20,true>", "avg_launch_us": round(us5s, 2),
+                                    "training_variant": {"kernel": "wdsr_fwd_stream12_kernel<24,144,20,true>", "avg_launch_us": round(us5s, 2),
                                                          "frac": round(alg5 / (us5s * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
             del a5, b5, c5, ts5
         else:

@@ -96,10 +96,11 @@ static int launch_fwd_rs(const void* x, void* ya, void* yb, const void* wa, cons
     // whole 48-wide images, at least one per CU and the last round of workgroups reasonably full: the streaming kernel
     // (csrc/wdsr_fwd_stream.h: no halo recompute, one barrier per band), with or without the saved t images
     if (fwd_stream_applies(N, H, W)) {
-#ifdef SR_FORCE_STREAM8                                 // (tools/build_variant.sh: A/B timing of the eight-wave form)
+#if defined(SR_FORCE_STREAM8) || defined(SR_DEBUG_STAMPS)   // (variant / diagnostic builds: the eight-wave form, one block's whole weight set per wave)
+#ifdef SR_FORCE_STREAM8
       static const bool eight = true;
 #else
-      static const bool eight = SR_AB("SR_STREAM8");   // (diagnostic build: the eight-wave form, one block's whole weight set per wave)
+      static const bool eight = SR_AB("SR_STREAM8");
 #endif
       if (eight) {
         if (tsa && tsb)
@@ -108,7 +109,11 @@ static int launch_fwd_rs(const void* x, void* ya, void* yb, const void* wa, cons
         else
           hipLaunchKernelGGL((wdsr_fwd_stream_kernel<F, E, L, false>), dim3(256), dim3(512), 0, st, (const T*)x, (T*)ya, (T*)yb, (const T*)wa,
                              (const T*)wb, cia, cib, (T*)nullptr, (T*)nullptr, N, H);
-      } else if (tsa && tsb)
+        SR_HIP_CHECK_LAUNCH();
+        return 0;
+      }
+#endif
+      if (tsa && tsb)
         hipLaunchKernelGGL((wdsr_fwd_stream12_kernel<F, E, L, true>), dim3(256), dim3(768), 0, st, (const T*)x, (T*)ya, (T*)yb, (const T*)wa,
                            (const T*)wb, cia, cib, (T*)tsa, (T*)tsb, N, H);
       else
@@ -141,6 +146,23 @@ static int launch_fwd_rs(const void* x, void* ya, void* yb, const void* wa, cons
       return 0;
     }
   }
+#if defined(SR_FORCE_RS16) || defined(SR_DEBUG_STAMPS)  // (tools/build_variant.sh / diagnostic build: the sixteen-wave form, A/B timing only)
+#ifdef SR_FORCE_RS16
+  static const bool rs16 = true;
+#else
+  static const bool rs16 = SR_AB("SR_RS16");
+#endif
+  if (rs16) {
+    if (tsa && (NBLK == 1 || tsb))
+      hipLaunchKernelGGL((wdsr_fwd_rs16_kernel<F, E, L, NBLK, true>), dim3(tiles_x * tiles_y, N), dim3(1024), 0, st, (const T*)x, (T*)ya,
+                         (T*)yb, (const T*)wa, (const T*)wb, cia, cib, (T*)tsa, (T*)tsb, H, W, tiles_x);
+    else
+      hipLaunchKernelGGL((wdsr_fwd_rs16_kernel<F, E, L, NBLK, false>), dim3(tiles_x * tiles_y, N), dim3(1024), 0, st, (const T*)x, (T*)ya,
+                         (T*)yb, (const T*)wa, (const T*)wb, cia, cib, (T*)tsa, (T*)tsb, H, W, tiles_x);
+    SR_HIP_CHECK_LAUNCH();
+    return 0;
+  }
+#endif
   if (tsa && (NBLK == 1 || tsb))
     hipLaunchKernelGGL((wdsr_fwd_rs_kernel<F, E, L, NBLK, true>), dim3(tiles_x * tiles_y, N), dim3(512), 0, st, (const T*)x, (T*)ya,
                        (T*)yb, (const T*)wa, (const T*)wb, cia, cib, (T*)tsa, (T*)tsb, H, W, tiles_x);

@@ -17,6 +17,7 @@
 //     zero padding and for the "ones" channel that carries conv1's bias.
 // Products, k-order and roundings are those of wdsr_block_fwd_kernel: results are bit-identical to it.
 #pragma once
+#include <type_traits>
 #include "wdsr_block.h"
 
 #ifdef SR_RS_NO_SETPRIO
@@ -552,6 +553,207 @@ __global__ __launch_bounds__(512) void wdsr_fwd_rs_kernel(const __bf16* __restri
     rw_phase_b<C, KXL, C::TW, C::TH * C::TW, 0, NW>(TT, X1, ONES, nullptr, yb + img, rwb, H, W, ty0, tx0, wave, lane, [](int, int) {});
   }
   SR_STAMP();
+}
+
+// =============================================================================================
+// SIXTEEN waves, weights read from LDS at use (round 3 experiment, per-tile launches).  With one tile per CU a phase has 9-14
+// pixel tiles: eight waves take them in two rounds, each a dependent LDS -> MFMA -> convert -> MFMA -> store chain, and a wave
+// that runs one tile uses each weight fragment ONCE -- loading it into a register first moves exactly the bytes a read at
+// use moves.  Here every pixel tile of a phase has its own wave (four per SIMD, 128 VGPRs), the weight fragment of an MFMA is
+// read from LDS one e-tile (conv1 / conv2) or four k-steps (3x3) ahead of it, and nothing is prefetched across phases.
+// Same products in the same order: bit-identical to wdsr_fwd_rs_kernel.
+// =============================================================================================
+template <typename C>
+SR_DEV f32x16 rw_t_tile_lds(const bf16x8 (&xb)[C::KS1], const __bf16* wl, int lane, const float* cl, int hh) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  static_assert(C::KS1 == 2 && C::FOLD_B1, "two conv1 k-steps per e-tile, b1 in the ones channel");
+  RwA<C> w;                                            // a bag of values: each fragment lives from its read to its MFMA
+  constexpr int W2 = C::NET * C::KS1;                  // index of w2[0] in load_one's numbering
+  auto need = [&](int et) {                            // the fragments iteration `et` multiplies with (et = -1: the prologue)
+    if (et < 0) { w.load_one(wl, lane, 0); w.load_one(wl, lane, 1); return; }
+    if (et + 1 < C::NET) { w.load_one(wl, lane, 2 * (et + 1)); w.load_one(wl, lane, 2 * (et + 1) + 1); }
+    if (et > 0 && 2 * et - 1 < C::KS2) w.load_one(wl, lane, W2 + 2 * et - 1);
+    if (2 * et < C::KS2) w.load_one(wl, lane, W2 + 2 * et);
+  };
+  f32x16 tacc = load_cinit(cl, hh);
+  auto cvt4 = [&](const f32x16& a, int base) {
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      __bf16 lo, hi;
+      cvt_pair<__bf16>(lo, hi, a[base + j], a[base + j + 1]);
+      f[j] = lo;
+      f[j + 1] = hi;
+    }
+    return f;
+  };
+  auto relu8 = [&](bf16x8 f) {
+    s16x8 v = __builtin_bit_cast(s16x8, f);
+    const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_bit_cast(bf16x8, __builtin_elementwise_max(v, z));
+  };
+  need(-1);
+  need(0);
+  f32x16 h = zero16();
+  h = mma16<__bf16>(w.w1[0], xb[0], h);
+  h = mma16<__bf16>(w.w1[1], xb[1], h);
+  bf16x8 f1prev = {};
+#pragma unroll
+  for (int et = 0; et < C::NET; ++et) {
+    const bool more = et + 1 < C::NET;
+    f32x16 hn = h;
+    if (more) need(et + 1);                                                                     // <= 4 LDS reads, one iteration ahead
+    else if (2 * C::NET - 1 < C::KS2) w.load_one(wl, lane, W2 + 2 * C::NET - 1);
+    if (more) hn = mma16<__bf16>(w.w1[2 * (et + 1)], xb[0], zero16());                          // MFMA
+    bf16x8 f0 = cvt4(h, 0);                                                                     // 4 VALU
+    if (more) hn = mma16<__bf16>(w.w1[2 * (et + 1) + 1], xb[1], hn);                            // MFMA
+    f0 = relu8(f0);                                                                             // 4 VALU
+    if (et > 0 && 2 * (et - 1) + 1 < C::KS2) tacc = mma16<__bf16>(w.w2[2 * et - 1], f1prev, tacc);   // MFMA
+    bf16x8 f1 = cvt4(h, 8);                                                                     // 4 VALU
+    if (2 * et < C::KS2) tacc = mma16<__bf16>(w.w2[2 * et], f0, tacc);                          // MFMA
+    f1prev = relu8(f1);                                                                         // 4 VALU
+    h = hn;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);    // 4 VALU
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // 1 LDS read
+    }
+  }
+  if (2 * (C::NET - 1) + 1 < C::KS2) tacc = mma16<__bf16>(w.w2[2 * C::NET - 1], f1prev, tacc);
+  return tacc;
+}
+
+template <typename C, typename A, int AHEAD>
+SR_DEV f32x16 rw_b_chain_lds(const A& a, const __bf16* wl, int lane, f32x16 acc) {
+  constexpr int KS = C::KS3D;
+  RwB<C> w;
+  bf16x8 f[KS];
+#pragma unroll
+  for (int s = 0; s < AHEAD; ++s) {
+    w.load_one(wl, lane, s);
+    f[s] = a.frag(s);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    acc = mma16<__bf16>(w.w3[s], f[s], acc);
+    if (s + AHEAD < KS) {
+      w.load_one(wl, lane, s + AHEAD);
+      f[s + AHEAD] = a.frag(s + AHEAD);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return acc;
+}
+
+template <int F, int E, int L, int NBLK, bool SAVE_T>
+__global__ __launch_bounds__(1024) void wdsr_fwd_rs16_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ ya,
+                                                             __bf16* __restrict__ yb, const __bf16* __restrict__ wa,
+                                                             const __bf16* __restrict__ wb, const float* __restrict__ cia,
+                                                             const float* __restrict__ cib, __bf16* __restrict__ tsa,
+                                                             __bf16* __restrict__ tsb, int H, int W, int tiles_x) {
+  typedef BlockCfg<F, E, L> C;
+  typedef RsCfg<F, E, L, NBLK> R;
+  constexpr int NW = 16;
+  __shared__ __attribute__((aligned(16))) char smem_raw[R::LDS_BYTES];
+  __bf16* const X0 = reinterpret_cast<__bf16*>(smem_raw);
+  __bf16* const TT = X0 + R::X0_ELEMS;
+  __bf16* const X1 = TT + R::TT_ELEMS;
+  __bf16* const WL = X1 + R::X1_ELEMS;
+  __bf16* const ONES = WL + NBLK * R::W_ELEMS;
+  float* const CL = reinterpret_cast<float*>(ONES + R::ONES_ELEMS);
+  constexpr int KXL = R::KXL;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+  const size_t img = (size_t)n * H * W * F;
+  const size_t tile_g = (size_t)n * gridDim.x + tile;
+
+  auto stage_pieces = [&](int lo, int hi) {              // (as in wdsr_fwd_rs_kernel)
+    const char* zeros = reinterpret_cast<const char*>(g_sr_const_chunks) + 16;
+    const int y0 = ty0 - NBLK, x0 = tx0 - NBLK;
+    const int lq = lane / C::FC, lc = lane - lq * C::FC;
+#pragma unroll 1
+    for (int p = lo + ((wave - lo) & (NW - 1)); p < hi; p += NW) {
+      if (p < R::P_C) {
+        const int px_ = p * R::PXP + lq;
+        const int py = px_ / R::rw(0), pxx = px_ - py * R::rw(0);
+        const int Y = y0 + py, X = x0 + pxx;
+        const char* src = zeros;
+        if (px_ < R::np(0) && Y >= 0 && Y < H && X >= 0 && X < W)
+          src = reinterpret_cast<const char*>(x + img + ((size_t)Y * W + X) * C::F + lc * 8);
+        dma_piece16(src, lds_addr(X0) + p * (R::PXP * C::FC * 16));
+      } else if (p < R::P_W) {
+        const int k = p - R::P_C, blk = k / (R::CL_FLOATS / 64), i = (k % (R::CL_FLOATS / 64)) * 64 + lane;
+        const float* tab = (NBLK > 1 && blk == 1) ? cib : cia;
+        const char* src = i < C::CINIT_FWD ? reinterpret_cast<const char*>(tab + i) : zeros + (lane & 3) * 4;
+        dma_piece4(src, lds_addr(CL) + k * 256);
+      } else {
+        const int fr = p - R::P_W;
+        const __bf16* wsrc = (NBLK > 1 && fr >= R::NFR) ? wb + (size_t)R::src_frag(fr - R::NFR) * 512 : wa + (size_t)R::src_frag(fr) * 512;
+        dma_piece16(reinterpret_cast<const char*>(wsrc + lane * 8), lds_addr(WL) + fr * 1024);
+      }
+    }
+  };
+  stage_pieces(0, R::P_W1);
+  if (tid < 8) ONES[tid] = tid == 0 ? (__bf16)1.f : (__bf16)0.f;
+  wait_vmcnt<0>();
+  __syncthreads();
+  if constexpr (NBLK > 1) stage_pieces(R::P_W1, R::P_END);
+
+  __bf16* const tsa_tile = SAVE_T ? tsa + tile_g * (C::TH * C::TW) * C::LP : nullptr;
+  __bf16* const tsb_tile = (SAVE_T && NBLK > 1) ? tsb + tile_g * (C::TH * C::TW) * C::LP : nullptr;
+
+  auto phase_a = [&](auto rw_c, auto np_c, auto halo_c, const __bf16* Xin, const __bf16* wl, const float* cl, __bf16* ts_tile, bool join_dma) {
+    constexpr int RW = decltype(rw_c)::value, NP = decltype(np_c)::value, HALO = decltype(halo_c)::value, NT = (NP + 31) / 32;
+    bool waited = false;
+#pragma unroll 1
+    for (int t_ = wave; t_ < NT; t_ += NW) {
+      const RwPix p = rw_pix_a<C, RW, NP, HALO>(t_ * 32 + r, H, W, ty0, tx0);
+      bf16x8 xb[C::KS1];
+      rw_x_frags<C, KXL>(xb, Xin, ONES, p.hp, hh);
+      const f32x16 t = rw_t_tile_lds<C>(xb, wl, lane, cl, hh);
+      if (join_dma && !waited) { wait_vmcnt<0>(); waited = true; }     // block 1's weight pieces (before this wave's first global store)
+      rw_store_t<C, SAVE_T>(t, p, TT, ts_tile, hh);
+    }
+    if (join_dma && !waited) wait_vmcnt<0>();
+  };
+  auto phase_b = [&](auto rwo_c, auto npo_c, auto halo_c, const __bf16* Xin, __bf16* Xnext, __bf16* yout, const __bf16* wl) {
+    constexpr int RWO = decltype(rwo_c)::value, NPO = decltype(npo_c)::value, HALOO = decltype(halo_c)::value, NT = (NPO + 31) / 32;
+    constexpr int RWI = RWO + 2;
+    typedef RwBAddrD<C, RWI> A;
+    const bool to_global = yout != nullptr;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yout, 0, to_global ? H * W * C::F * 2 : 0, 0x00020000);
+#pragma unroll 1
+    for (int t_ = wave; t_ < NT; t_ += NW) {
+      const RwPixB p = rw_pix_b<C, KXL, RWO, NPO, HALOO>(t_, r, H, W, ty0, tx0);
+      A a;
+      a.init(TT, ONES, p.hy, p.hx, hh);
+      const f32x16 acc = rw_b_chain_lds<C, A, 4>(a, wl + (size_t)RwB<C>::OFF * 0, lane, rw_resid_init<C>(Xin + ((p.hy + 1) * RWI + p.hx + 1) * KXL, hh));
+      rw_store_y<C>(acc, p, Xnext, yrs, to_global, hh);
+    }
+  };
+  typedef std::integral_constant<int, R::rw(0)> RW0;
+  typedef std::integral_constant<int, R::np(0)> NP0;
+  typedef std::integral_constant<int, NBLK> H0;
+  phase_a(RW0{}, NP0{}, H0{}, X0, WL, CL, tsa_tile, NBLK > 1);
+  __syncthreads();
+  if constexpr (NBLK == 1) {
+    phase_b(std::integral_constant<int, C::TW>{}, std::integral_constant<int, C::TH * C::TW>{}, std::integral_constant<int, 0>{}, X0, nullptr,
+            yb + img, WL);
+  } else {
+    typedef std::integral_constant<int, R::rw(1)> RW1;
+    typedef std::integral_constant<int, R::np(1)> NP1;
+    typedef std::integral_constant<int, NBLK - 1> H1;
+    phase_b(RW1{}, NP1{}, H1{}, X0, X1, ya ? ya + img : nullptr, WL);
+    __syncthreads();
+    phase_a(RW1{}, NP1{}, H1{}, X1, WL + R::W_ELEMS, CL + R::CL_FLOATS, tsb_tile, false);
+    __syncthreads();
+    phase_b(std::integral_constant<int, C::TW>{}, std::integral_constant<int, C::TH * C::TW>{}, std::integral_constant<int, 0>{}, X1, nullptr,
+            yb + img, WL + R::W_ELEMS);
+  }
 }
 
 // =============================================================================================
