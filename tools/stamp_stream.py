@@ -1,10 +1,7 @@
 """Diagnostic: one steady-state round (round 8) of the streaming forward kernel from explicit stamp slots.
     python -m mobilesuperresolution_amd.build --debug; python tools/stamp_stream.py [batch]"""
-import os
-os.environ.setdefault("SR_STREAM8", "1")   # the stamped kernel is the eight-wave form (diagnostic build)
 import os, sys
 os.environ["SR_HOTPATH_DEBUG_LIB"] = "1"
-import os
 os.environ.setdefault("SR_STREAM8", "1")   # the stamped kernel is the eight-wave form (diagnostic build)
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
