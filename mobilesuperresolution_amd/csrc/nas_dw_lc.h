@@ -216,11 +216,13 @@ __global__ __launch_bounds__(512) void nas_dw_fwd_lc_kernel(const __bf16* __rest
 // tile [k][pixel][32] instead of 2-byte global stores; after one barrier the tile is (a) written to V with 16-byte stores
 // (the backward needs it) and (b) the B operand of the pointwise part (nas_pw_fwd_kernel's arithmetic, reading LDS it did
 // not have to stage).  Saves the second launch, its 14 MB read of V and its staging latency; results are bit-identical to the
-// two-kernel route.  9 waves: 24 row units over 9 waves are the same three rounds as over 8, and the pointwise part has
-// one 32-pixel tile per wave.  grid = (tiles, N).
+// two-kernel route.  The pointwise part has one 32-pixel tile per wave.  grid = (tiles, N).
 // ---------------------------------------------------------------------------------------------
+// twelve waves (round 3): the 24 row units of the stencil phase are two rounds instead of three (nine waves before; 140 VGPRs fit three
+// waves per SIMD); the pointwise part uses the first nine
+constexpr int NAS_BLOCK_FWD_THREADS = 768;
 template <int F>
-__global__ __launch_bounds__(576) void nas_block_fwd_kernel(const __bf16* __restrict__ yin, __bf16* __restrict__ V,
+__global__ __launch_bounds__(NAS_BLOCK_FWD_THREADS) void nas_block_fwd_kernel(const __bf16* __restrict__ yin, __bf16* __restrict__ V,
                                                             __bf16* __restrict__ y, const float* __restrict__ dwp,
                                                             const __bf16* __restrict__ frags, const float* __restrict__ tabs,
                                                             const float* __restrict__ scal, int H, int W, int tiles_x, long vstride) {
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(576) void nas_block_fwd_kernel(const __bf16* __rest
   typedef NasLcCfg<F> D;
   typedef typename FragOf<T>::type FragT;
   typedef typename FragOf<T>::half_type HalfT;
-  constexpr int NTHREADS = 576;
+  constexpr int NTHREADS = NAS_BLOCK_FWD_THREADS;
   __shared__ __attribute__((aligned(16))) unsigned XE[D::XP_DW];
   __shared__ __attribute__((aligned(16))) unsigned XO[D::XP_DW];
   __shared__ __attribute__((aligned(16))) unsigned WP[D::NWP * 32];
@@ -286,7 +288,8 @@ __global__ __launch_bounds__(576) void nas_block_fwd_kernel(const __bf16* __rest
       *reinterpret_cast<FragT*>(V + k * vstride + img + ((size_t)Y * W + X) * F + c * 8) =
           *reinterpret_cast<const FragT*>(VT + k * C::VT_ELEMS + pc * 32 + c * 8);
   }
-  // (b) pointwise + mix: y = mg*yin + beta2 * ms * sum_k p_k relu(pw_k V_k + bp_k)
+  // (b) pointwise + mix: y = mg*yin + beta2 * ms * sum_k p_k relu(pw_k V_k + bp_k): one 32-pixel tile per wave
+  if (wave >= C::NPT_O) return;                       // (wave-uniform; no barrier follows)
   const int r = lane & 31, hh = half;
   const int ot = wave;
   const int oy = (ot / (C::TW / 8)) * 4 + (r >> 3), ox = (ot % (C::TW / 8)) * 8 + (r & 7);
@@ -359,40 +362,33 @@ SR_DEV void nas_lc_bwd_unit(float (&g)[6], float& dbsum, const unsigned* base, c
   }
 }
 
+// (twelve waves, two row units each: round 3; eight waves of three units before)
+constexpr int NAS_DW_BWD_THREADS = 768;
 template <int F>
-__global__ __launch_bounds__(512) void nas_dw_bwd_lc_kernel(const __bf16* __restrict__ yin, const __bf16* __restrict__ GZ,
+__global__ __launch_bounds__(NAS_DW_BWD_THREADS) void nas_dw_bwd_lc_kernel(const __bf16* __restrict__ yin, const __bf16* __restrict__ GZ,
                                                             const __bf16* __restrict__ gy, __bf16* __restrict__ gyin,
                                                             const float* __restrict__ dwp, float* __restrict__ partial, int N, int H,
                                                             int W, int tiles_x, int tiles_per_img, long vstride) {
   typedef NasCfg<F> C;
   typedef NasLcCfg<F> D;
-  static_assert(D::UW / 2 == 6 && D::NUNIT == 24, "three units of six columns per wave");
+  constexpr int NT = NAS_DW_BWD_THREADS, NWV = NT / 64, UPW = D::NUNIT / NWV;
+  static_assert(D::UW / 2 == 6 && D::NUNIT == NWV * UPW, "units of six columns, the same number per wave");
   __shared__ __attribute__((aligned(16))) unsigned XE[D::XP_DW];
   __shared__ __attribute__((aligned(16))) unsigned XO[D::XP_DW];
   __shared__ __attribute__((aligned(16))) unsigned WP[D::NWP * 32];
-  __shared__ float GB[18 * 512];
+  __shared__ float GB[UPW * 6 * NT];
   const int tid = threadIdx.x, lane = tid & 63, ch = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   SR_STAMP_DECL;
   SR_STAMP();
-  nas_pack_weights<F, 512>(WP, dwp, tid, true);        // flipped: the data gradient
+  nas_pack_weights<F, NT>(WP, dwp, tid, true);        // flipped: the data gradient
   if ((int)blockIdx.x < N * tiles_per_img) {           // the first tile's first image is staged under the same barrier
     const int t0 = blockIdx.x, n0 = t0 / tiles_per_img, tile0 = t0 - n0 * tiles_per_img;
-    nas_stage_pairs<F, 512>(XE, XO, GZ + (size_t)n0 * H * W * F, nullptr, H, W, (tile0 / tiles_x) * C::TH, (tile0 % tiles_x) * C::TW, tid);
+    nas_stage_pairs<F, NT>(XE, XO, GZ + (size_t)n0 * H * W * F, nullptr, H, W, (tile0 / tiles_x) * C::TH, (tile0 % tiles_x) * C::TW, tid);
   }
   __syncthreads();
-  NasLcW w;
-  w.template load<F>(WP, ch);
-  // NasLcW keeps w5 / w3 compact ([5][3], [3][2]); the unit routine indexes [ty][t] with rows of 4
-  unsigned w5[5][4], w3[3][4];
-#pragma unroll
-  for (int r = 0; r < 5; ++r)
-#pragma unroll
-    for (int t = 0; t < 3; ++t) w5[r][t] = w.w5[r][t];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) w3[r][t] = w.w3[r][t];
+  // the stencil of a pass is read from the packed table at the start of the pass (one stencil live at a time: with all 83 weight
+  // pairs resident the kernel needs 185 VGPRs, two waves per SIMD; so it fits three)
   const float mgc = dwp[C::MG + ch], msc = dwp[C::MS + ch];
   const unsigned* X = half ? XO : XE;
   const bool chan = ch < F;
@@ -407,19 +403,26 @@ __global__ __launch_bounds__(512) void nas_dw_bwd_lc_kernel(const __bf16* __rest
       SR_STAMP();
       if (!(k == 0 && t == (int)blockIdx.x)) {
         __syncthreads();                               // the previous pass is through with the pair images
-        nas_stage_pairs<F, 512>(XE, XO, GZ + k * vstride + img, nullptr, H, W, ty0, tx0, tid);
+        nas_stage_pairs<F, NT>(XE, XO, GZ + k * vstride + img, nullptr, H, W, ty0, tx0, tid);
         __syncthreads();
       }
       SR_STAMP();
+      const int KSZ = 3 + 2 * k, KNP = k == 0 ? 2 : (k == 1 ? 3 : 4), KOFF = k == 0 ? D::W3P : (k == 1 ? D::W5P : D::W7P);   // (k: unrolled)
+      unsigned wk[7][4];                               // rows of 4: the unit routine indexes [ty][t]
+#pragma unroll
+      for (int r = 0; r < 7; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (r < KSZ && t < KNP) wk[r][t] = WP[(KOFF + r * KNP + t) * 32 + ch];
 #pragma unroll 1
-      for (int i = 0; i < 3; ++i) {
-        const int u = wave + 8 * i;
+      for (int i = 0; i < UPW; ++i) {
+        const int u = wave + NWV * i;
         const int oy = u >> 1, ox0 = (u & 1) * D::UW + half;
         const unsigned* base = X + (size_t)((oy * C::PW + ox0) >> 1) * F + (chan ? ch : 0);
         // this lane's six partial g_br values of the unit wait in LDS between the passes ([unit][column][thread]: conflict-free)
         float g[6];
 #pragma unroll
-        for (int s = 0; s < 6; ++s) g[s] = k == 0 ? 0.f : GB[(i * 6 + s) * 512 + tid];
+        for (int s = 0; s < 6; ++s) g[s] = k == 0 ? 0.f : GB[(i * 6 + s) * NT + tid];
         // last pass: this unit's yin / gy values are fetched before the 7x7 window work, not after it
         __bf16 yq[6], gq[6];
         if (k == 2) {
@@ -432,12 +435,12 @@ __global__ __launch_bounds__(512) void nas_dw_bwd_lc_kernel(const __bf16* __rest
             gq[s] = gy[o];
           }
         }
-        if (k == 0) nas_lc_bwd_unit<3>(g, db[0], base, w3, F, C::PW / 2);
-        else if (k == 1) nas_lc_bwd_unit<5>(g, db[1], base, w5, F, C::PW / 2);
-        else nas_lc_bwd_unit<7>(g, db[2], base, w.w7, F, C::PW / 2);
+        if (k == 0) nas_lc_bwd_unit<3>(g, db[0], base, wk, F, C::PW / 2);
+        else if (k == 1) nas_lc_bwd_unit<5>(g, db[1], base, wk, F, C::PW / 2);
+        else nas_lc_bwd_unit<7>(g, db[2], base, wk, F, C::PW / 2);
         if (k < 2) {
 #pragma unroll
-          for (int s = 0; s < 6; ++s) GB[(i * 6 + s) * 512 + tid] = g[s];
+          for (int s = 0; s < 6; ++s) GB[(i * 6 + s) * NT + tid] = g[s];
         } else {                                       // last pass: the epilogue of the data gradient for these six pixels
 #pragma unroll
           for (int s = 0; s < 6; ++s) {
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(512) void nas_dw_bwd_lc_kernel(const __bf16* __rest
   if (tid < 160) {
     float s = 0.f;
 #pragma unroll
-    for (int wv = 0; wv < 8; ++wv) s += red[wv * 160 + tid];
+    for (int wv = 0; wv < NWV; ++wv) s += red[wv * 160 + tid];
     partial[(size_t)blockIdx.x * C::DWB_SLAB + 83 * 32 + tid] = s;       // dbd[3][32] | sA[32] | sB[32]
   }
   SR_STAMP();

@@ -767,8 +767,8 @@ extern "C" int sr_nas_dw_bwd(const void* yin, const void* GZ, const void* gy, vo
   if (dtype == SR_DTYPE_BF16 && !valu_dw && (F == 24 || F == 32)) {      // lane = channel (csrc/nas_dw_lc.h); the dW part of the slab is sr_nas_dw_wgrad's
     typedef NasCfg<24> C;
     const int tx = (W + C::TW - 1) / C::TW, tpi = tx * ((H + C::TH - 1) / C::TH);
-    if (F == 24) hipLaunchKernelGGL((nas_dw_bwd_lc_kernel<24>), dim3(wgs), dim3(512), 0, st, (const __bf16*)yin, (const __bf16*)GZ, (const __bf16*)gy, (__bf16*)gyin, dwp, partial, N, H, W, tx, tpi, vs);
-    else hipLaunchKernelGGL((nas_dw_bwd_lc_kernel<32>), dim3(wgs), dim3(512), 0, st, (const __bf16*)yin, (const __bf16*)GZ, (const __bf16*)gy, (__bf16*)gyin, dwp, partial, N, H, W, tx, tpi, vs);
+    if (F == 24) hipLaunchKernelGGL((nas_dw_bwd_lc_kernel<24>), dim3(wgs), dim3(NAS_DW_BWD_THREADS), 0, st, (const __bf16*)yin, (const __bf16*)GZ, (const __bf16*)gy, (__bf16*)gyin, dwp, partial, N, H, W, tx, tpi, vs);
+    else hipLaunchKernelGGL((nas_dw_bwd_lc_kernel<32>), dim3(wgs), dim3(NAS_DW_BWD_THREADS), 0, st, (const __bf16*)yin, (const __bf16*)GZ, (const __bf16*)gy, (__bf16*)gyin, dwp, partial, N, H, W, tx, tpi, vs);
     SR_HIP_CHECK_LAUNCH();
     return 0;
   }
@@ -1133,8 +1133,8 @@ extern "C" int sr_nas_body_fwd(void* ys, void* V, const float* dwp, long dwp_bs,
       const float* tb_i = (const float*)((const char*)tabs + (size_t)i * tabs_bs);
       const float* sc_i = (const float*)((const char*)scal + (size_t)i * scal_bs);
       hipStream_t st = (hipStream_t)stream;
-      if (F == 24) hipLaunchKernelGGL((nas_block_fwd_kernel<24>), g, dim3(576), 0, st, (const __bf16*)yi, (__bf16*)Vi, (__bf16*)(yi + act), dw_i, fr_i, tb_i, sc_i, H, W, tx, vs);
-      else hipLaunchKernelGGL((nas_block_fwd_kernel<32>), g, dim3(576), 0, st, (const __bf16*)yi, (__bf16*)Vi, (__bf16*)(yi + act), dw_i, fr_i, tb_i, sc_i, H, W, tx, vs);
+      if (F == 24) hipLaunchKernelGGL((nas_block_fwd_kernel<24>), g, dim3(NAS_BLOCK_FWD_THREADS), 0, st, (const __bf16*)yi, (__bf16*)Vi, (__bf16*)(yi + act), dw_i, fr_i, tb_i, sc_i, H, W, tx, vs);
+      else hipLaunchKernelGGL((nas_block_fwd_kernel<32>), g, dim3(NAS_BLOCK_FWD_THREADS), 0, st, (const __bf16*)yi, (__bf16*)Vi, (__bf16*)(yi + act), dw_i, fr_i, tb_i, sc_i, H, W, tx, vs);
       SR_HIP_CHECK_LAUNCH();
       continue;
     }
