@@ -422,8 +422,8 @@ def main():
             big = 512                                         # the same kernel with 16 workgroups per CU
             a5 = torch.randn(big, LR, LR, UNITS, device=dev).to(tdt)
             b5, c5 = torch.empty_like(a5), torch.empty_like(a5)
-            keep, reps = reps, 32
-            for _ in range(2):                                # 32 launches of ~0.1 ms per chain: let the clocks settle on this grid
+            keep, reps = reps, 64
+            for _ in range(4):                                # 64 launches of ~0.06 ms per chain: let the clocks settle on this grid
                 rs_chain(2, a5, b5, c5, big)
             us5 = timed(lambda: rs_chain(2, a5, b5, c5, big))
             ts5 = torch.empty((2, big, tiles, 288, 24), device=dev, dtype=torch.bfloat16)
