@@ -7,6 +7,7 @@
 // to 32) and 24 output channels.  The bias rides on a ones channel (index ONES, a spare slot of the
 // 32-wide LDS row) at the centre tap.  Activation: 0 none, 1 ReLU, 2 LeakyReLU(0.1).
 #pragma once
+#include <type_traits>
 #include "wdsr_block.h"
 #include "flow_warp.h"
 
@@ -499,6 +500,153 @@ __global__ __launch_bounds__((64 * C3Pair::NPT_H)) void c3_resblock_fwd_kernel(c
       }
     }
   }
+}
+
+// =============================================================================================
+// TWO ResidualBlockNoBN per launch (bf16, round 3): a C4 frame step is 8 + 8 of these ~9 us launches, each one round of 256
+// workgroups and almost all of it launch ramp, staging and drain.  Four convs chained through LDS on shrinking regions of ONE
+// common grid (the tile + 4-pixel halo, 24 x 24): conv1 on [1, 23)^2 (16 pixel tiles) -> t_a, conv2 + x on [2, 22)^2 (13) -> y_a
+// IN PLACE over x, conv3 on [3, 21)^2 (11) -> t_b over t_a, conv4 + y_a on the core [4, 20)^2 (8) -> y_b: 48 pixel tiles of MFMAs
+// where two launches run 38, for one staging, one ramp and one drain.  16 waves, one pixel tile per wave and stage.  t_a, y_a, t_b,
+// y_b are written for the backward exactly where the per-block launches write them; the same products in the same order and the
+// same bf16 rounding points: bit-identical to two c3_resblock_fwd launches.
+// Measured at C4: 16.6 us against 2 x 8.7 us -- 5 %, not the 30 % the launch count suggests: these kernels read BOTH MFMA operands
+// from LDS (2 KB per MFMA; a wave has one pixel tile per stage, so register-resident weights would move the same bytes), i.e. a
+// stage of 16 pixel tiles is 576 KB of LDS reads = 1.9 us at 128 B/clk, four stages 5.7 us: LDS bandwidth, not launches, is what a
+// residual block costs here.  The backward-data kernel therefore stays at one block per launch.
+// =============================================================================================
+struct C3Quad {
+  typedef C3Cfg C;
+  static constexpr int GW = C::TW + 8, GH = C::TH + 8, NG = GW * GH;         // 24 x 24 = 576
+  static constexpr int G_ELEMS = (NG + 2) * 32;
+  static constexpr int NWAVES = ((GW - 2) * (GH - 2) + 31) / 32;             // conv1's pixel tiles: 16
+  static constexpr int LDS_BYTES = (2 * G_ELEMS + 4 * C::KSF * 512) * 2;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <typename T>
+__global__ __launch_bounds__((64 * C3Quad::NWAVES)) void c3_resblock2_fwd_kernel(const T* __restrict__ x, T* __restrict__ tmid_a,
+                                                                               T* __restrict__ y_a, T* __restrict__ tmid_b,
+                                                                               T* __restrict__ y_b, const T* __restrict__ w_,
+                                                                               long o1, long o2, long o3, long o4, int H, int W,
+                                                                               int tiles_x, C3Dir dir) {
+  typedef C3Cfg C;
+  typedef C3Quad Q;
+  typedef typename FragOf<T>::type FragT;
+  typedef typename FragOf<T>::half_type HalfT;
+  static_assert(sizeof(T) == 2, "bf16 only (LDS budget)");
+  constexpr int NTHREADS = 64 * Q::NWAVES;
+  __shared__ __attribute__((aligned(16))) T smem[2 * Q::G_ELEMS + 4 * C::KSF * 512];
+  T* const XB = smem;                       // x on the grid, then y_a in place
+  T* const TB = XB + Q::G_ELEMS;            // t_a, then t_b
+  T* const WL = TB + Q::G_ELEMS;
+  const T* const wbase = w_ + c3_dir_off(dir, blockIdx.y);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
+  const size_t img = (size_t)n * H * W * C::CO;
+  WSrc<T, true> ws[4];
+  const long offs[4] = {o1, o2, o3, o4};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    ws[k].p = WL + k * C::KSF * 512;
+    stage_weights<T, NTHREADS>(WL + k * C::KSF * 512, wbase + offs[k], C::KSF, tid);
+  }
+  {   // x on the grid: [NG + 2][32], 24 channels + ones channel at 24; the t buffer: ones channel and zero padding of every row
+    constexpr int TOTAL = (Q::NG + 2) * 4, ITER = (TOTAL + NTHREADS - 1) / NTHREADS;
+    FragT v[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + it * NTHREADS;
+      const int p = idx >> 2, c = idx & 3;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[it][j] = (T)0.f;
+      if (idx < TOTAL && p < Q::NG && c < 3) {
+        const int py = p / Q::GW, px = p - py * Q::GW;
+        const int Y = ty0 - 4 + py, X = tx0 - 4 + px;
+        if (Y >= 0 && Y < H && X >= 0 && X < W) v[it] = *reinterpret_cast<const FragT*>(x + img + ((size_t)Y * W + X) * C::CO + c * 8);
+      }
+      if (c == 3) v[it][0] = (T)1.f;
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + it * NTHREADS;
+      if (idx < TOTAL) {
+        *reinterpret_cast<FragT*>(XB + idx * 8) = v[it];
+        FragT z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = (T)0.f;
+        if ((idx & 3) == 3) z[0] = (T)1.f;
+        *reinterpret_cast<FragT*>(TB + idx * 8) = z;
+      }
+    }
+  }
+  __syncthreads();
+
+  // one conv stage: output region [LO, GW - LO)^2 of the grid, one pixel tile per wave; IN -> acc; the epilogue is the caller's
+  auto conv = [&](auto lo_c, const T* IN, const WSrc<T, true>& wk, int& gp, bool& live, bool& inimg, bool& core, int& Y, int& X) {
+    constexpr int LO = decltype(lo_c)::value, RW = Q::GW - 2 * LO, NP = RW * (Q::GH - 2 * LO);
+    const int hp = wave * 32 + r;
+    live = hp < NP;
+    const int hpc = live ? hp : 0;
+    const int hy = hpc / RW, hx = hpc - hy * RW;
+    const int gy = LO + hy, gx = LO + hx;
+    gp = gy * Q::GW + gx;
+    Y = ty0 - 4 + gy;
+    X = tx0 - 4 + gx;
+    inimg = Y >= 0 && Y < H && X >= 0 && X < W;
+    core = inimg && gy >= 4 && gy < 4 + C::TH && gx >= 4 && gx < 4 + C::TW;
+    const int base = gp - Q::GW - 1;
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int s = 0; s < C::KSF; ++s) {
+      const int q = 2 * s + hh, tap = q >> 2, c = q & 3;
+      acc = mma16<T>(wk.get(s, lane), lds_chunk<T>(IN, (base + (tap / 3) * Q::GW + (tap % 3)) * 32 + c * 8), acc);
+    }
+    return acc;
+  };
+  auto relu_stage = [&](auto lo_c, const T* IN, T* OUT, const WSrc<T, true>& wk, T* tmid) {
+    constexpr int LO = decltype(lo_c)::value, NT = ((Q::GW - 2 * LO) * (Q::GH - 2 * LO) + 31) / 32;
+    if (wave >= NT) return;
+    int gp, Y, X;
+    bool live, inimg, core;
+    const f32x16 acc = conv(lo_c, IN, wk, gp, live, inimg, core, Y, X);
+    if (live) {
+#pragma unroll
+      for (int g = 0; g < C::COC; ++g) {
+        HalfT v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = inimg ? (T)c3_act<1>(acc[4 * g + j]) : (T)0.f;
+        *reinterpret_cast<HalfT*>(OUT + gp * 32 + g * 8 + hh * 4) = v;
+        if (core) *reinterpret_cast<HalfT*>(tmid + img + ((size_t)Y * W + X) * C::CO + g * 8 + hh * 4) = v;
+      }
+    }
+  };
+  auto res_stage = [&](auto lo_c, const T* IN, T* RES, const WSrc<T, true>& wk, T* yout, bool to_lds) {
+    constexpr int LO = decltype(lo_c)::value, NT = ((Q::GW - 2 * LO) * (Q::GH - 2 * LO) + 31) / 32;
+    if (wave >= NT) return;
+    int gp, Y, X;
+    bool live, inimg, core;
+    const f32x16 acc = conv(lo_c, IN, wk, gp, live, inimg, core, Y, X);
+    if (live) {
+#pragma unroll
+      for (int g = 0; g < C::COC; ++g) {
+        const HalfT rv = *reinterpret_cast<const HalfT*>(RES + gp * 32 + g * 8 + hh * 4);
+        HalfT v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = inimg ? (T)(acc[4 * g + j] + (float)rv[j]) : (T)0.f;
+        if (to_lds) *reinterpret_cast<HalfT*>(RES + gp * 32 + g * 8 + hh * 4) = v;       // in place: this pixel's own row
+        if (core) *reinterpret_cast<HalfT*>(yout + img + ((size_t)Y * W + X) * C::CO + g * 8 + hh * 4) = v;
+      }
+    }
+  };
+  relu_stage(std::integral_constant<int, 1>{}, XB, TB, ws[0], tmid_a);
+  __syncthreads();
+  res_stage(std::integral_constant<int, 2>{}, TB, XB, ws[1], y_a, true);
+  __syncthreads();
+  relu_stage(std::integral_constant<int, 3>{}, XB, TB, ws[2], tmid_b);
+  __syncthreads();
+  res_stage(std::integral_constant<int, 4>{}, TB, XB, ws[3], y_b, false);
 }
 
 // backward-data of one ResidualBlockNoBN per launch: gt = conv2^T(g) on the tile + 1-pixel halo (written once for

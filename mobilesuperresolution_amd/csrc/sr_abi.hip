@@ -23,8 +23,8 @@
 extern "C" int sr_abi_version(void) { return 13; }
 
 // A/B switches between a kernel and the one it replaced are live in the diagnostic build only (build.py --debug); in the product
-// library they are the constant false, and the kernels only they reach are not instantiated.  (SR_NAS_FWD_SPLIT / SR_NAS_BWD_SPLIT
-// stay: the parity tests chain the fused NAS kernels to the separately tested ones through them.)
+// library they are the constant false, and the kernels only they reach are not instantiated.  (SR_NAS_FWD_SPLIT / SR_NAS_BWD_SPLIT /
+// SR_C3_ONE_BLOCK_PER_LAUNCH stay: the parity tests chain the fused kernels to the separately tested ones through them.)
 #ifdef SR_DEBUG_STAMPS
 #define SR_AB(name) (getenv(name) != nullptr)
 #else
@@ -577,8 +577,17 @@ static int c3_trunk_fwd_t(const void* x0, const sr_c3_warp_t* warp, void* acts_,
   int rc;
   if ((rc = c3_fwd_t<T>(x0, nullptr, acts, blob + boff[0], N, H, W, ci0, 2, st, warp, dir))) return rc;
   for (int i = 0; i < nb; ++i) {
-    if constexpr (sizeof(T) == 2) {                    // one launch per residual block
+    if constexpr (sizeof(T) == 2) {
       const C3Grid g = c3_grid(N, H, W);
+      const bool single = getenv("SR_C3_ONE_BLOCK_PER_LAUNCH") != nullptr;   // (read per call: the parity test chains the two forms)
+      if (!single && i + 1 < nb) {                     // two residual blocks per launch
+        hipLaunchKernelGGL((c3_resblock2_fwd_kernel<T>), g.grid, dim3(64 * C3Quad::NWAVES), 0, st, acts + i * act, mids + i * act,
+                           acts + (i + 1) * act, mids + (i + 1) * act, acts + (i + 2) * act, blob, boff[1 + 2 * i], boff[2 + 2 * i],
+                           boff[3 + 2 * i], boff[4 + 2 * i], H, W, g.tx, dir);
+        SR_HIP_CHECK_LAUNCH();
+        ++i;
+        continue;
+      }
       hipLaunchKernelGGL((c3_resblock_fwd_kernel<T>), g.grid, dim3(64 * C3Pair::NPT_H), 0, st, acts + i * act, mids + i * act,
                          acts + (i + 1) * act, blob + boff[1 + 2 * i], blob + boff[2 + 2 * i], H, W, g.tx, dir);
       SR_HIP_CHECK_LAUNCH();
