@@ -83,6 +83,24 @@ static bool fwd_stream_applies(long N, int H, int W) {
   return N * 10 >= rounds * 256 * 7;
 }
 
+// the sixteen-wave form (weights read from LDS at use): the route of the 32-unit network, whose weight sets do not fit the
+// register-resident kernels; at 24 units in variant / diagnostic builds only (A/B timing)
+template <int F, int E, int L, int NBLK>
+static int launch_fwd_rs16(const void* x, void* ya, void* yb, const void* wa, const void* wb, const float* cia, const float* cib,
+                           void* tsa, void* tsb, int N, int H, int W, hipStream_t st) {
+  typedef BlockCfg<F, E, L> C;
+  typedef __bf16 T;
+  const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
+  if (tsa && (NBLK == 1 || tsb))
+    hipLaunchKernelGGL((wdsr_fwd_rs16_kernel<F, E, L, NBLK, true>), dim3(tiles_x * tiles_y, N), dim3(1024), 0, st, (const T*)x, (T*)ya,
+                       (T*)yb, (const T*)wa, (const T*)wb, cia, cib, (T*)tsa, (T*)tsb, H, W, tiles_x);
+  else
+    hipLaunchKernelGGL((wdsr_fwd_rs16_kernel<F, E, L, NBLK, false>), dim3(tiles_x * tiles_y, N), dim3(1024), 0, st, (const T*)x, (T*)ya,
+                       (T*)yb, (const T*)wa, (const T*)wb, cia, cib, (T*)tsa, (T*)tsb, H, W, tiles_x);
+  SR_HIP_CHECK_LAUNCH();
+  return 0;
+}
+
 // forward with register-resident weights (csrc/wdsr_fwd_rs.h): nblk = 1 (x -> yb) or 2 (x -> ya -> yb)
 template <int F, int E, int L, int NBLK>
 static int launch_fwd_rs(const void* x, void* ya, void* yb, const void* wa, const void* wb, const float* cia, const float* cib,
@@ -152,16 +170,7 @@ static int launch_fwd_rs(const void* x, void* ya, void* yb, const void* wa, cons
 #else
   static const bool rs16 = SR_AB("SR_RS16");
 #endif
-  if (rs16) {
-    if (tsa && (NBLK == 1 || tsb))
-      hipLaunchKernelGGL((wdsr_fwd_rs16_kernel<F, E, L, NBLK, true>), dim3(tiles_x * tiles_y, N), dim3(1024), 0, st, (const T*)x, (T*)ya,
-                         (T*)yb, (const T*)wa, (const T*)wb, cia, cib, (T*)tsa, (T*)tsb, H, W, tiles_x);
-    else
-      hipLaunchKernelGGL((wdsr_fwd_rs16_kernel<F, E, L, NBLK, false>), dim3(tiles_x * tiles_y, N), dim3(1024), 0, st, (const T*)x, (T*)ya,
-                         (T*)yb, (const T*)wa, (const T*)wb, cia, cib, (T*)tsa, (T*)tsb, H, W, tiles_x);
-    SR_HIP_CHECK_LAUNCH();
-    return 0;
-  }
+  if (rs16) return launch_fwd_rs16<F, E, L, NBLK>(x, ya, yb, wa, wb, cia, cib, tsa, tsb, N, H, W, st);
 #endif
   if (tsa && (NBLK == 1 || tsb))
     hipLaunchKernelGGL((wdsr_fwd_rs_kernel<F, E, L, NBLK, true>), dim3(tiles_x * tiles_y, N), dim3(512), 0, st, (const T*)x, (T*)ya,
@@ -180,12 +189,14 @@ extern "C" int sr_wdsr_fwd_rs(const void* x, void* ya, void* yb, const void* wa,
   hipStream_t st = (hipStream_t)stream;
   if (F == 24 && nblk == 2) return launch_fwd_rs<24, 144, 20, 2>(x, ya, yb, wa, wb, cia, cib, tsa, tsb, N, H, W, st);
   if (F == 24 && nblk == 1) return launch_fwd_rs<24, 144, 20, 1>(x, nullptr, yb, wa, nullptr, cia, nullptr, tsa, nullptr, N, H, W, st);
+  if (F == 32 && nblk == 2) return launch_fwd_rs16<32, 192, 26, 2>(x, ya, yb, wa, wb, cia, cib, tsa, tsb, N, H, W, st);
+  if (F == 32 && nblk == 1) return launch_fwd_rs16<32, 192, 26, 1>(x, nullptr, yb, wa, nullptr, cia, nullptr, tsa, nullptr, N, H, W, st);
   return -1;
 }
 extern "C" int sr_wdsr_block2_fwd(const void* x, void* ya, void* yb, const void* wa, const void* wb, const float* cia,
                                   const float* cib, void* tsa, void* tsb, int N, int H, int W, int F, int dtype,
                                   sr_stream_t stream) {
-  if (F != 24) return (!x || !yb || !wa || !wb || !cia || !cib || N <= 0 || H <= 0 || W <= 0 || N > 65535) ? -2 : -1;
+  if (F != 24 && F != 32) return (!x || !yb || !wa || !wb || !cia || !cib || N <= 0 || H <= 0 || W <= 0 || N > 65535) ? -2 : -1;
   return sr_wdsr_fwd_rs(x, ya, yb, wa, wb, cia, cib, tsa, tsb, 2, N, H, W, F, dtype, stream);
 }
 extern "C" int sr_wdsr_fwd_rs_repeat(void* x, void* ya, void* yb, const void* wa, const void* wb, const float* cia,
@@ -872,7 +883,10 @@ extern "C" int sr_wdsr_net_forward(const sr_wdsr_net_t* n, int flags, sr_stream_
   char* cur = acts;
   // inference over many tiles per CU: the persistent two-block launches (csrc/wdsr_fwd_rs.h) beat the single-block ones
   // again (0.29 vs 0.27 of the roof at batch 512); with saved images (training) the large grids stay on single blocks
-  const bool pairs = net_uses_pairs(n) || (n->F == 24 && n->dtype == SR_DTYPE_BF16 &&
+  // 32 units (round 3): two blocks per forward launch at launch-bound grids as well (the sixteen-wave kernel; SR_F32_ONE_BLOCK=1, read
+  // per call for the parity test, keeps the one-block kernels); its backward stays one block per launch
+  const bool pairs32 = n->F == 32 && n->dtype == SR_DTYPE_BF16 && net_tiles(n) <= 384 && !getenv("SR_F32_ONE_BLOCK");
+  const bool pairs = net_uses_pairs(n) || pairs32 || (n->F == 24 && n->dtype == SR_DTYPE_BF16 &&
                                            ((!save_acts && net_tiles(n) >= 768) || fwd_stream_applies(n->N, n->H, n->W)));
   const bool saved = net_saves_side_images(n, false);
   const size_t side = side_image_bytes(n);

@@ -35,12 +35,19 @@ struct BlockCfg {
   // packed weight blob (fragments of 512 elements)
   static constexpr int W1_OFF = 0, W2_OFF = NET * KS1, W3_OFF = W2_OFF + KS2, NFRAG_FWD = W3_OFF + KS3;
   static constexpr int CINIT_FWD = 32 + (FOLD_B1 ? 0 : NET * 32);
-  // "dense K" form of the 3x3 conv (csrc/wdsr_fwd_rs.h, packing.py W3D): the three taps of a window row are 3 L contiguous
-  // channels of the t image, cut into 4-channel chunks (15 at L = 20) + one spare = 4 k-steps per window row; the bias rides on
-  // a "ones" chunk in the last row's spare slot, the residual is the accumulator's initial value.  12 k-steps where KS3 = 15.
-  static constexpr int LC = L / 4;                                 // 4-channel chunks per tap
-  static constexpr bool DENSE3 = (L % 4 == 0) && (3 * LC + 1 == 16);
-  static constexpr int KS3D = DENSE3 ? 12 : 0;
+  // "dense K" form of the 3x3 conv (csrc/wdsr_fwd_rs.h, packing.py W3D): the three taps of a window row are 3 TD contiguous
+  // channels of the t image (TD = L rounded up to a multiple of 4: 20 at 24 units, 28 at 32 units), cut into 4-channel chunks
+  // (15 / 21) + a spare one = KPR k-steps per window row (4 / 6); lane half hh of k-step q reads the chunks HALF hh + 2 q and
+  // HALF hh + 2 q + 1 (16 contiguous bytes); the bias rides on a "ones" chunk in the last row's chunk slot 3 LCD, which is the SECOND
+  // chunk of half 1 in k-step QONE; the residual is the accumulator's initial value.  12 / 18 k-steps where KS3 = 15 / 19.
+  static constexpr int TD = (L + 3) / 4 * 4;                       // t channels per LDS row of the dense form
+  static constexpr int LCD = TD / 4;                               // 4-channel chunks per tap
+  static constexpr int KPR = (3 * LCD + 1 + 3) / 4;                // k-steps per window row
+  static constexpr int HALF = 2 * KPR;                             // chunk slots per lane half and row
+  static constexpr int QONE = (3 * LCD - HALF) / 2;                // the k-step (within the row) whose half-1 second chunk is slot 3 LCD
+  static constexpr bool DENSE3 = 3 * LCD >= HALF && (3 * LCD - HALF) % 2 == 1;
+  static constexpr int KS3D = DENSE3 ? 3 * KPR : 0;
+  static constexpr int LC = L / 4;                                 // (24 units: LC = LCD)
 };
 
 // stage the halo'd x tile [NPXH_PAD][KX] into LDS: zero outside the image, ones channel at index F.

@@ -81,8 +81,8 @@ template <int F_, int E_, int L_, int NBLK_> struct RsCfg {
   // bias is ONE 16-byte constant in LDS that every lane half needing it reads (a broadcast)
   static constexpr int KXL = C::F;
   static constexpr int X0_ELEMS = npad(0) * KXL;                       // staged x
-  static_assert(C::DENSE3, "the register-resident forward runs the 3x3 conv in its dense-K form (L % 4 == 0)");
-  static constexpr int TD = C::L;                                      // t channels per LDS row: the real ones only (40 bytes at L = 20)
+  static_assert(C::DENSE3, "the register-resident forward runs the 3x3 conv in its dense-K form");
+  static constexpr int TD = C::TD;                                     // t channels per LDS row: the real ones (40 bytes at L = 20; 26 + 2 at 32 units)
   static constexpr int TT_ELEMS = npad(0) * TD;                        // t of the current block
   static constexpr int X1_ELEMS = NBLK > 1 ? npad(1) * KXL : 0;        // block 0's output = block 1's input
   static constexpr int ONES_ELEMS = 8;                                 // [1, 0, 0, 0 | 0, 0, 0, 0]: conv1's ones chunk (16 B) = the 3x3's ones chunk + zero chunk (8 B each)
@@ -91,7 +91,11 @@ template <int F_, int E_, int L_, int NBLK_> struct RsCfg {
   static constexpr int W_ELEMS = NFR * 512;
   static constexpr int src_frag(int fr) { return fr < NFR_A ? fr : W3D_SRC + (fr - NFR_A); }
   static constexpr int CL_FLOATS = (C::CINIT_FWD + 63) / 64 * 64;      // whole 64-float DMA pieces per block
-  static constexpr int LDS_BYTES = (X0_ELEMS + TT_ELEMS + X1_ELEMS + NBLK * W_ELEMS + ONES_ELEMS) * 2 + NBLK * CL_FLOATS * 4;
+  // one weight region per block where they fit (24 units); otherwise (32 units, two blocks: 2 x 42 KB) ONE region that block 1's
+  // fragments take over phase by phase once block 0's phase is through with them (wdsr_fwd_rs16_kernel)
+  static constexpr bool REUSE_W = (X0_ELEMS + TT_ELEMS + X1_ELEMS + NBLK * W_ELEMS + ONES_ELEMS) * 2 + NBLK * CL_FLOATS * 4 > 160 * 1024;
+  static constexpr int W_REGIONS = REUSE_W ? 1 : NBLK;
+  static constexpr int LDS_BYTES = (X0_ELEMS + TT_ELEMS + X1_ELEMS + W_REGIONS * W_ELEMS + ONES_ELEMS) * 2 + NBLK * CL_FLOATS * 4;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   // staging piece list (one piece = one wave-instruction of LDS-DMA), dealt round-robin to the waves in this order:
   // x region | C-init tables | block 0's weights || block 1's weights.  Only what precedes `||` is waited for
@@ -99,8 +103,9 @@ template <int F_, int E_, int L_, int NBLK_> struct RsCfg {
   // x pieces: 21 pixels each (63 chunks) + the first chunk of the 22nd, which the next piece rewrites with the same
   // bytes: every lane then owns a FIXED (pixel offset, chunk) pair and a piece costs one division by the row width
   // (64 arbitrary chunks per piece cost two divisions and the staging loop was VALU-bound: 275 of a wave's 714 VALU ops)
-  static constexpr int PXP = 63 / C::FC, P_X = 0, NPX = (npad(0) + PXP - 1) / PXP;
-  static_assert(C::FC == 3, "piece geometry assumes 3 chunks per pixel");
+  // (32 units: 16 pixels of 4 chunks = 64 lanes exactly)
+  static constexpr int PXP = (C::FC == 3 ? 63 : 64) / C::FC, P_X = 0, NPX = (npad(0) + PXP - 1) / PXP;
+  static_assert(C::FC == 3 || C::FC == 4, "piece geometry: 3 or 4 chunks per pixel");
   static_assert(NPX * PXP * C::FC * 16 + 16 <= (X0_ELEMS + TT_ELEMS) * 2, "the last x piece may spill into the (not yet written) t image only");
   static constexpr int P_C = P_X + NPX, NPC = NBLK * (CL_FLOATS / 64);
   static constexpr int P_W = P_C + NPC, P_W1 = P_W + NFR, P_END = P_W + NBLK * NFR;
@@ -225,11 +230,12 @@ SR_DEV void rw_store_t(const f32x16& tacc, const RwPix& p, __bf16* TT, __bf16* t
       for (int j = 0; j < 4; ++j) v[g][j] = (__bf16)0.f;
     }
   }
-  // LDS rows hold the L real channels (dense-K operand of the 3x3 conv); the ones channel and the padding stay out
+  // LDS rows hold TD channels (dense-K operand of the 3x3 conv): the L real ones; at 32 units also the ones channel and one zero (26 -> 28:
+  // both meet zero weights); whatever lies behind stays out
 #pragma unroll
   for (int g = 0; g < C::CPT; ++g) {
-    if (g * 8 + 8 <= C::L) *reinterpret_cast<bf16x4*>(TT + p.hp * C::L + g * 8 + hh * 4) = v[g];
-    else if (g * 8 + 4 <= C::L) { if (hh == 0) *reinterpret_cast<bf16x4*>(TT + p.hp * C::L + g * 8) = v[g]; }
+    if (g * 8 + 8 <= C::TD) *reinterpret_cast<bf16x4*>(TT + p.hp * C::TD + g * 8 + hh * 4) = v[g];
+    else if (g * 8 + 4 <= C::TD) { if (hh == 0) *reinterpret_cast<bf16x4*>(TT + p.hp * C::TD + g * 8) = v[g]; }
   }
   if constexpr (SAVE_T) {
     if (p.tso >= 0) {
@@ -304,23 +310,23 @@ SR_DEV void rw_phase_a(const __bf16* Xin, const __bf16* ones, __bf16* TT, const 
 // W3D; in the last row that slot reads a "ones" chunk instead, whose weight is b3.  Against the 8-channel chunks of
 // wdsr_block.h (t rows padded to LP = 24 with the ones channel, residual as identity chunks): 12 k-steps instead of 15.
 template <typename C, int RWI> struct RwBAddrD {
-  static constexpr int TD = C::L, KS = C::KS3D;
-  static_assert(C::DENSE3 && KS == 12, "dense-K layout: 16 chunk slots per window row");
+  static constexpr int TD = C::TD, KS = C::KS3D, KPR = C::KPR;
+  static_assert(C::DENSE3, "dense-K layout");
   typedef __attribute__((address_space(3))) const volatile bf16x4* lds_chunk_p;
   // VOLATILE 8-byte LDS reads: hipcc otherwise merges two of them -- the two of one k-step, or the first chunks of two k-steps --
   // into one ds_read2_b64, which takes 8 LDS cycles where two ds_read_b64 take 4 (at one read pair per MFMA and four SIMDs
   // that is the whole LDS issue rate).
   lds_chunk_p b0;         // first chunk of this lane half in window row 0
-  lds_chunk_p last;       // second chunk of the last k-step: half 0 its chunk 7, half 1 the ones chunk
+  lds_chunk_p last;       // second chunk of k-step QONE of the last row: half 0 its own chunk, half 1 the ones chunk
   SR_DEV void init(const __bf16* TT, const __bf16* ones, int hy, int hx, int hh) {
-    const __bf16* g0 = TT + (hy * RWI + hx) * TD + hh * 32;
+    const __bf16* g0 = TT + (hy * RWI + hx) * TD + hh * (C::HALF * 4);
     b0 = (lds_chunk_p)(g0);
-    last = (lds_chunk_p)(hh ? ones : g0 + 2 * RWI * TD + 3 * 8 + 4);
+    last = (lds_chunk_p)(hh ? ones : g0 + 2 * RWI * TD + C::QONE * 8 + 4);
   }
   SR_DEV bf16x8 frag(int s) const {
-    const int off = ((s / 4) * RWI * TD + (s % 4) * 8) / 4;      // in 4-element chunks
+    const int off = ((s / KPR) * RWI * TD + (s % KPR) * 8) / 4;  // in 4-element chunks
     const bf16x4 lo = b0[off];
-    const bf16x4 hi = s == KS - 1 ? *last : b0[off + 1];
+    const bf16x4 hi = s == 2 * KPR + C::QONE ? *last : b0[off + 1];
     bf16x8 f;
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(512) void wdsr_fwd_rs_kernel(const __bf16* __restri
 template <typename C>
 SR_DEV f32x16 rw_t_tile_lds(const bf16x8 (&xb)[C::KS1], const __bf16* wl, int lane, const float* cl, int hh) {
   typedef __attribute__((ext_vector_type(8))) short s16x8;
-  static_assert(C::KS1 == 2 && C::FOLD_B1, "two conv1 k-steps per e-tile, b1 in the ones channel");
+  static_assert(C::KS1 == 2, "two conv1 k-steps per e-tile");
   RwA<C> w;                                            // a bag of values: each fragment lives from its read to its MFMA
   constexpr int W2 = C::NET * C::KS1;                  // index of w2[0] in load_one's numbering
   auto need = [&](int et) {                            // the fragments iteration `et` multiplies with (et = -1: the prologue)
@@ -594,7 +600,8 @@ SR_DEV f32x16 rw_t_tile_lds(const bf16x8 (&xb)[C::KS1], const __bf16* wl, int la
   };
   need(-1);
   need(0);
-  f32x16 h = zero16();
+  auto conv1_init = [&](int et) { return C::FOLD_B1 ? zero16() : load_cinit(cl + 32 + et * 32, hh); };   // (b1: ones channel or table)
+  f32x16 h = conv1_init(0);
   h = mma16<__bf16>(w.w1[0], xb[0], h);
   h = mma16<__bf16>(w.w1[1], xb[1], h);
   bf16x8 f1prev = {};
@@ -604,7 +611,7 @@ SR_DEV f32x16 rw_t_tile_lds(const bf16x8 (&xb)[C::KS1], const __bf16* wl, int la
     f32x16 hn = h;
     if (more) need(et + 1);                                                                     // <= 4 LDS reads, one iteration ahead
     else if (2 * C::NET - 1 < C::KS2) w.load_one(wl, lane, W2 + 2 * C::NET - 1);
-    if (more) hn = mma16<__bf16>(w.w1[2 * (et + 1)], xb[0], zero16());                          // MFMA
+    if (more) hn = mma16<__bf16>(w.w1[2 * (et + 1)], xb[0], conv1_init(et + 1));                // MFMA
     bf16x8 f0 = cvt4(h, 0);                                                                     // 4 VALU
     if (more) hn = mma16<__bf16>(w.w1[2 * (et + 1) + 1], xb[1], hn);                            // MFMA
     f0 = relu8(f0);                                                                             // 4 VALU
@@ -661,7 +668,8 @@ __global__ __launch_bounds__(1024) void wdsr_fwd_rs16_kernel(const __bf16* __res
   __bf16* const TT = X0 + R::X0_ELEMS;
   __bf16* const X1 = TT + R::TT_ELEMS;
   __bf16* const WL = X1 + R::X1_ELEMS;
-  __bf16* const ONES = WL + NBLK * R::W_ELEMS;
+  __bf16* const ONES = WL + R::W_REGIONS * R::W_ELEMS;
+  __bf16* const WL1 = R::REUSE_W ? WL : WL + R::W_ELEMS;             // where block 1's fragments go
   float* const CL = reinterpret_cast<float*>(ONES + R::ONES_ELEMS);
   constexpr int KXL = R::KXL;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
@@ -693,7 +701,7 @@ __global__ __launch_bounds__(1024) void wdsr_fwd_rs16_kernel(const __bf16* __res
       } else {
         const int fr = p - R::P_W;
         const __bf16* wsrc = (NBLK > 1 && fr >= R::NFR) ? wb + (size_t)R::src_frag(fr - R::NFR) * 512 : wa + (size_t)R::src_frag(fr) * 512;
-        dma_piece16(reinterpret_cast<const char*>(wsrc + lane * 8), lds_addr(WL) + fr * 1024);
+        dma_piece16(reinterpret_cast<const char*>(wsrc + lane * 8), lds_addr(WL) + ((R::REUSE_W && fr >= R::NFR) ? fr - R::NFR : fr) * 1024);
       }
     }
   };
@@ -701,7 +709,7 @@ __global__ __launch_bounds__(1024) void wdsr_fwd_rs16_kernel(const __bf16* __res
   if (tid < 8) ONES[tid] = tid == 0 ? (__bf16)1.f : (__bf16)0.f;
   wait_vmcnt<0>();
   __syncthreads();
-  if constexpr (NBLK > 1) stage_pieces(R::P_W1, R::P_END);
+  if constexpr (NBLK > 1 && !R::REUSE_W) stage_pieces(R::P_W1, R::P_END);
 
   __bf16* const tsa_tile = SAVE_T ? tsa + tile_g * (C::TH * C::TW) * C::LP : nullptr;
   __bf16* const tsb_tile = (SAVE_T && NBLK > 1) ? tsb + tile_g * (C::TH * C::TW) * C::LP : nullptr;
@@ -731,14 +739,14 @@ __global__ __launch_bounds__(1024) void wdsr_fwd_rs16_kernel(const __bf16* __res
       const RwPixB p = rw_pix_b<C, KXL, RWO, NPO, HALOO>(t_, r, H, W, ty0, tx0);
       A a;
       a.init(TT, ONES, p.hy, p.hx, hh);
-      const f32x16 acc = rw_b_chain_lds<C, A, 4>(a, wl + (size_t)RwB<C>::OFF * 0, lane, rw_resid_init<C>(Xin + ((p.hy + 1) * RWI + p.hx + 1) * KXL, hh));
+      const f32x16 acc = rw_b_chain_lds<C, A, 4>(a, wl, lane, rw_resid_init<C>(Xin + ((p.hy + 1) * RWI + p.hx + 1) * KXL, hh));
       rw_store_y<C>(acc, p, Xnext, yrs, to_global, hh);
     }
   };
   typedef std::integral_constant<int, R::rw(0)> RW0;
   typedef std::integral_constant<int, R::np(0)> NP0;
   typedef std::integral_constant<int, NBLK> H0;
-  phase_a(RW0{}, NP0{}, H0{}, X0, WL, CL, tsa_tile, NBLK > 1);
+  phase_a(RW0{}, NP0{}, H0{}, X0, WL, CL, tsa_tile, NBLK > 1 && !R::REUSE_W);
   __syncthreads();
   if constexpr (NBLK == 1) {
     phase_b(std::integral_constant<int, C::TW>{}, std::integral_constant<int, C::TH * C::TW>{}, std::integral_constant<int, 0>{}, X0, nullptr,
@@ -747,12 +755,18 @@ __global__ __launch_bounds__(1024) void wdsr_fwd_rs16_kernel(const __bf16* __res
     typedef std::integral_constant<int, R::rw(1)> RW1;
     typedef std::integral_constant<int, R::np(1)> NP1;
     typedef std::integral_constant<int, NBLK - 1> H1;
+    // (one weight region: block 1's conv1 / conv2 fragments take over block 0's while its 3x3 runs, block 1's W3D takes over block
+    // 0's while block 1's conv1 / conv2 run; each is waited for in front of the barrier that precedes its first use)
+    if constexpr (R::REUSE_W) stage_pieces(R::P_W1, R::P_W1 + R::NFR_A);
     phase_b(RW1{}, NP1{}, H1{}, X0, X1, ya ? ya + img : nullptr, WL);
+    if constexpr (R::REUSE_W) wait_vmcnt<0>();
     __syncthreads();
-    phase_a(RW1{}, NP1{}, H1{}, X1, WL + R::W_ELEMS, CL + R::CL_FLOATS, tsb_tile, false);
+    if constexpr (R::REUSE_W) stage_pieces(R::P_W1 + R::NFR_A, R::P_END);
+    phase_a(RW1{}, NP1{}, H1{}, X1, WL1, CL + R::CL_FLOATS, tsb_tile, false);
+    if constexpr (R::REUSE_W) wait_vmcnt<0>();
     __syncthreads();
     phase_b(std::integral_constant<int, C::TW>{}, std::integral_constant<int, C::TH * C::TW>{}, std::integral_constant<int, 0>{}, X1, nullptr,
-            yb + img, WL + R::W_ELEMS);
+            yb + img, WL1);
   }
 }
 

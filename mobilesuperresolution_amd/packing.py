@@ -178,7 +178,7 @@ def block_tables(F: int, E: int, L: int):
     """Tables for all residual-block kernels (forward, backward-data, weight-gradient).
 
     Blob sections (in 512-element fragments), forward first so wdsr_block_fwd_kernel's offsets hold:
-      W1 | W2 | W3 | W3T | W2T | W1T | ID | W2N | W3D (L = 20 only)
+      W1 | W2 | W3 | W3T | W2T | W1T | ID | W2N | W3D
     C-init floats: b2c[32] | b1c[NET][32] (only when b1 is not folded) | b1n[NET*32] (same condition).
     """
     fwd = block_fwd_tables(F, E, L)
@@ -228,18 +228,24 @@ def block_tables(F: int, E: int, L: int):
     # pixel's first chunk) gets zero weights, except in the last row where the kernel reads a "ones" chunk there whose first
     # slot carries b3.  12 k-steps where the 8-channel chunks of W3 (LP = 24 with the ones channel, plus the identity chunks
     # of the residual) need 15: the residual is the accumulator's initial value instead (csrc/wdsr_fwd_rs.h, rw_phase_b).
+    # General form (round 3, 32 units): TD = L rounded up to a multiple of 4 (channels >= L of a pixel get zero weights), LCD = TD / 4
+    # chunks per tap, KPR = ceil((3 LCD + 1) / 4) k-steps per window row, lane half hh of k-step q reads the chunk slots
+    # 2 KPR hh + 2 q + (j >> 2); the ones chunk is slot 3 LCD of the last row (BlockCfg::TD / LCD / KPR / HALF in csrc/wdsr_block.h).
     w3d = None
-    if 3 * (L // 4) + 1 == 16 and L % 4 == 0:
-        LC = L // 4
-        KS3D = 12
+    TD = (L + 3) // 4 * 4
+    LCD = TD // 4
+    KPR = (3 * LCD + 1 + 3) // 4
+    HALF = 2 * KPR
+    if 3 * LCD >= HALF and (3 * LCD - HALF) % 2 == 1:
+        KS3D = 3 * KPR
         s, r, hh, j = _grid(KS3D)
-        ky, q = s // 4, s % 4
-        rc = 8 * hh + 2 * q + (j >> 2)
+        ky, q = s // KPR, s % KPR
+        rc = HALF * hh + 2 * q + (j >> 2)
         jj = j & 3
-        tap, l = 3 * ky + np.minimum(rc, 3 * LC - 1) // LC, 4 * (rc % LC) + jj
+        tap, l = 3 * ky + np.minimum(rc, 3 * LCD - 1) // LCD, 4 * (rc % LCD) + jj
         rf = np.minimum(r, F - 1)
-        w3d = _sel((rc < 3 * LC) & (r < F), o["w3"] + (rf * L + np.minimum(l, L - 1)) * 9 + np.minimum(tap, 8), Z)
-        w3d = _sel((rc == 3 * LC) & (ky == 2) & (jj == 0) & (r < F), o["b3"] + rf, w3d)
+        w3d = _sel((rc < 3 * LCD) & (l < L) & (r < F), o["w3"] + (rf * L + np.minimum(l, L - 1)) * 9 + np.minimum(tap, 8), Z)
+        w3d = _sel((rc == 3 * LCD) & (ky == 2) & (jj == 0) & (r < F), o["b3"] + rf, w3d)
     else:
         KS3D = 0
 

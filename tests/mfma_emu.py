@@ -308,11 +308,19 @@ def emu_conv3_dense(t_nhwc, x_nhwc, packed_w3d, L, F, dtype="f32"):
     region (zeros outside the image), rows of L real channels; output tiles are 32 consecutive pixels of the H x W core region
     numbered row-major over a region of width RWO = W (region pixel (hy, hx) <-> window top-left t row (hy, hx))."""
     H, W, _ = t_nhwc.shape
-    RWO, RWI, TD = W, W + 2, L
+    TD = (L + 3) // 4 * 4                                            # BlockCfg::TD / LCD / KPR / HALF / QONE
+    LCD = TD // 4
+    KPR = (3 * LCD + 1 + 3) // 4
+    HALF = 2 * KPR
+    QONE = (3 * LCD - HALF) // 2
+    assert 3 * LCD >= HALF and (3 * LCD - HALF) % 2 == 1
+    RWO, RWI = W, W + 2
     NPI = (H + 2) * RWI
     T = np.zeros(((NPI + 31) // 32 * 32 + 32) * TD)                  # + slack rows, as the LDS image has behind it
     Tv = T[:NPI * TD].reshape(H + 2, RWI, TD)
-    Tv[1:H + 1, 1:W + 1] = rnd(t_nhwc, dtype)
+    Tv[1:H + 1, 1:W + 1, :L] = rnd(t_nhwc, dtype)
+    if TD > L:
+        Tv[1:H + 1, 1:W + 1, L] = 1.0                                # the kernel's t rows carry the ones channel there (zero weights)
     ones = np.zeros(8)
     ones[0] = 1.0
     X = rnd(x_nhwc, dtype)
@@ -328,13 +336,13 @@ def emu_conv3_dense(t_nhwc, x_nhwc, packed_w3d, L, F, dtype="f32"):
             for k in range(4):
                 f = 8 * g + 4 * HH + k
                 acc[:, 4 * g + k] = np.where(f < F, X[hy, hx, np.minimum(f, F - 1)], 0.0) if g < F // 8 else 0.0
-        b0 = (hy * RWI + hx) * TD + HH * 32
-        for s in range(12):
-            off = (s // 4) * RWI * TD + (s % 4) * 8
+        b0 = (hy * RWI + hx) * TD + HH * (HALF * 4)
+        for s in range(3 * KPR):
+            off = (s // KPR) * RWI * TD + (s % KPR) * 8
             b = np.zeros((64, 8))
             for l in range(64):
                 b[l, :4] = T[b0[l] + off:b0[l] + off + 4]
-                if s == 11 and HH[l]:
+                if s == 2 * KPR + QONE and HH[l]:
                     b[l, 4:] = ones[:4]
                 else:
                     b[l, 4:] = T[b0[l] + off + 4:b0[l] + off + 8]

@@ -89,10 +89,11 @@ def run_block_fwd_rs(x_nchw, src, f):
     return y.float().permute(0, 3, 1, 2).cpu()
 
 
-def test_block_fwd_rs_bf16_against_reference_golden(golden_dir):
-    """the graded kernel (wdsr_fwd_rs_kernel: register-resident weights, dense-K 3x3, residual as accumulator init) directly
-    against G2: same tolerance as the round-1 bf16 kernel (bf16 storage, 2^-8 relative)"""
-    f = 24
+@pytest.mark.parametrize("f", [24, 32])
+def test_block_fwd_rs_bf16_against_reference_golden(golden_dir, f):
+    """the graded kernel (wdsr_fwd_rs_kernel: register-resident weights, dense-K 3x3, residual as accumulator init; 32 units:
+    wdsr_fwd_rs16_kernel, sixteen waves, weights from LDS at use, 28-channel t rows) directly against G2: same tolerance as the
+    round-1 bf16 kernel (bf16 storage, 2^-8 relative)"""
     d = _load(golden_dir, f"g2_block_f{f}.npz")
     y = run_block_fwd_rs(d["x"], block_src(d), f)
     xr = d["x"].bfloat16().float()
@@ -234,7 +235,7 @@ def test_block_pair_kernel_bit_identical_to_two_launches(shape):
     _assert_same_up_to_summation_order(p2, y2, "block 1")
 
 
-@pytest.mark.parametrize("f,nblk", [(24, 1), (24, 2)])
+@pytest.mark.parametrize("f,nblk", [(24, 1), (24, 2), (32, 1), (32, 2)])
 @pytest.mark.parametrize("shape", [(3, 48, 48), (2, 20, 28), (1, 7, 9), (2, 37, 91)])
 def test_role_specialised_forward_matches_round1_kernels_and_itself(shape, f, nblk):
     """sr_wdsr_fwd_rs (register-resident weights, LDS-DMA staging, dense-K 3x3) against sr_wdsr_block_fwd launches (the same

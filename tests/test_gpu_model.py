@@ -382,3 +382,41 @@ def test_large_batch_training_on_the_streaming_kernel_equals_small_batches():
     assert torch.equal(big.detach(), torch.cat(outs))
     scale = float(g_acc.abs().max())
     assert float((g_big - g_acc).abs().max()) <= 2e-3 * scale and float((g_big - g_acc).norm()) <= 1e-3 * float(g_acc.norm())
+
+
+def test_32_units_two_blocks_per_forward_launch_equal_one_block_kernels(monkeypatch):
+    """32 units, bf16 (C3's width): the forward runs two blocks per launch on wdsr_fwd_rs16_kernel (sixteen waves, dense-K 3x3 on
+    28-channel t rows); SR_F32_ONE_BLOCK=1 keeps the round-1 one-block kernels.  Same products in another summation order: the
+    outputs agree up to one-ulp flips of the bf16 activations, the saved t images feed the same weight-gradient kernels, the
+    gradients agree within bf16 tolerance; the fused route also agrees with the fp32 parity mode like the one-block route does"""
+    torch.manual_seed(14)
+    ns = _ns(num_blocks=6, num_residual_units=32, hot_dtype="bf16")
+    m = _model(ns).train()
+    g = torch.Generator().manual_seed(15)
+    x = torch.rand(3, 3, 40, 52, generator=g).cuda()
+    hr = torch.rand(3, 3, 160, 208, generator=g).cuda()
+    res = {}
+    for key, env in (("pairs", None), ("single", "1")):
+        if env:
+            monkeypatch.setenv("SR_F32_ONE_BLOCK", env)
+        else:
+            monkeypatch.delenv("SR_F32_ONE_BLOCK", raising=False)
+        m.zero_grad(set_to_none=True)
+        y = m(x)
+        torch.nn.functional.l1_loss(y, hr).backward()
+        res[key] = (y.detach().clone(), m.flat.grad.clone())
+    monkeypatch.delenv("SR_F32_ONE_BLOCK", raising=False)
+    (yp, gp), (ys, gs) = res["pairs"], res["single"]
+    assert torch.isfinite(yp).all() and torch.isfinite(gp).all()
+    rel = ((yp - ys).norm() / ys.norm()).item()
+    grel = ((gp - gs).norm() / gs.norm()).item()
+    print(f"\n32 units, pairs vs one-block kernels: output rel L2 {rel:.2e}, flat gradient rel L2 {grel:.2e}")
+    assert rel <= 2e-3 and grel <= 3e-2
+    # against the fp32 parity mode on the same parameters
+    ns32 = _ns(num_blocks=6, num_residual_units=32)
+    a = _model(ns32).train()
+    a.load_state_dict(m.state_dict())
+    ya = a(x)
+    torch.nn.functional.l1_loss(ya, hr).backward()
+    assert ((yp - ya.detach()).norm() / ya.detach().norm()).item() <= 2e-2
+    assert ((gp - a.flat.grad).norm() / a.flat.grad.norm()).item() <= 6e-2

@@ -103,18 +103,21 @@ def test_block_bwd_tables_match_golden(golden_dir, f):
         assert err <= 1e-4 * exp.abs().max().item(), (k, err)
 
 
+@pytest.mark.parametrize("units", [24, 32])
 @pytest.mark.parametrize("dtype,tol", [("f32", 3e-6), ("bf16", 6e-3)])
-def test_dense_k_conv3_tables_match_golden(golden_dir, dtype, tol):
+def test_dense_k_conv3_tables_match_golden(golden_dir, dtype, tol, units):
     """W3D (packing.block_tables) + the dense-K addressing of csrc/wdsr_fwd_rs.h (RwBAddrD: 16 contiguous bytes per lane half
-    and k-step, the ones chunk in the last slot, the residual as accumulator init) against the reference block's own t -> y
-    (G2: y = conv3x3(t) + b3 + x)"""
-    d = _load(golden_dir, "g2_block_f24.npz")
-    tab = P.block_tables(24, 144, 20)
+    and k-step, the ones chunk in its slot of the last window row, the residual as accumulator init) against the reference block's
+    own t -> y (G2: y = conv3x3(t) + b3 + x); 24 units: 20-channel t rows, 12 k-steps; 32 units: 26 channels in 28-channel rows, 18"""
+    d = _load(golden_dir, f"g2_block_f{units}.npz")
+    E, Lc = units * 6, int(units * 6 * 0.84 // 6) if False else {24: 20, 32: 26}[units]
+    tab = P.block_tables(units, E, Lc)
     g = tab["geom"]
     src = block_src(d, g)
     sec = tab["sec"]
-    assert tab["KS3D"] == 12 and tab["nfrag"] == sec["W3D"] + 12
-    w3d = src[tab["w"]][sec["W3D"] * 512:(sec["W3D"] + 12) * 512]
+    ks3d = {24: 12, 32: 18}[units]
+    assert tab["KS3D"] == ks3d and tab["nfrag"] == sec["W3D"] + ks3d
+    w3d = src[tab["w"]][sec["W3D"] * 512:(sec["W3D"] + ks3d) * 512]
     t = d["t2"][0].permute(1, 2, 0).double().numpy() if "t2" in d else None
     x = d["x"][0].permute(1, 2, 0).double().numpy()
     if t is None:                                                    # the fixture names its intermediates differently: recompute t
@@ -124,7 +127,7 @@ def test_dense_k_conv3_tables_match_golden(golden_dir, dtype, tol):
         w2 = O.weight_norm(sd["body.2.weight_v"], sd["body.2.weight_g"])
         tt = Fn.conv2d(Fn.relu(Fn.conv2d(d["x"][:1], w1, sd["body.0.bias"])), w2, sd["body.2.bias"])
         t = tt[0].permute(1, 2, 0).double().numpy()
-    y = M.emu_conv3_dense(t, x, w3d, 20, 24, dtype=dtype)
+    y = M.emu_conv3_dense(t, x, w3d, Lc, units, dtype=dtype)
     import torch.nn.functional as Fn
     sd = {k[2:]: v for k, v in d.items() if k.startswith("p/")}
     w3 = O.weight_norm(sd["body.3.weight_v"], sd["body.3.weight_g"]).double()
