@@ -40,9 +40,10 @@ int sr_abi_version(void);
 int sr_wdsr_block_fwd(const void* x, void* y, const void* wblob, const float* cinit,
                       int N, int H, int W, int F, int dtype, sr_stream_t stream);
 
-/* Two consecutive residual blocks in one launch (bf16, F = 24 only; -1 otherwise): x -> ya (block A's
- * output, kept because backward needs every block input; NULL = do not store) -> yb.  Bit-identical to two sr_wdsr_block_fwd
- * calls; exists because a single block launch at batch 32 is bound by its fixed costs.  (= sr_wdsr_fwd_rs with nblk = 2.) */
+/* Two consecutive residual blocks in one launch (bf16, F = 24 or 32; -1 otherwise): x -> ya (block A's
+ * output, kept because backward needs every block input; NULL = do not store) -> yb.  Equal to two sr_wdsr_block_fwd
+ * calls up to the fp32 summation order of the 3x3 conv (dense-K form: the residual enters the sum first); exists because a
+ * single block launch at batch 32 is bound by its fixed costs.  (= sr_wdsr_fwd_rs with nblk = 2.) */
 int sr_wdsr_block2_fwd(const void* x, void* ya, void* yb, const void* wblob_a, const void* wblob_b,
                        const float* cinit_a, const float* cinit_b, void* tsave_a, void* tsave_b, int N, int H, int W,
                        int F, int dtype, sr_stream_t stream);
@@ -66,11 +67,12 @@ int sr_wdsr_block_wgrad_saved(const void* x, const void* dy, const void* tsave, 
                               int wgs, int N, int H, int W, int F, int dtype, long x_ls, long dy_ls, long side_ls,
                               long w_ls, long c_ls, sr_stream_t stream);
 
-/* Forward of nblk = 1 or 2 consecutive residual blocks with register-resident weights (bf16, F = 24 only; -1
- * otherwise): every wave keeps the weights of its current phase in registers, x / weights are staged by LDS-DMA
- * (csrc/wdsr_fwd_rs.h).  Same
- * arguments and bit-identical results as sr_wdsr_block_fwd (nblk = 1: x -> yb, the *_b / ya arguments unused)
- * and sr_wdsr_block2_fwd (nblk = 2). */
+/* Forward of nblk = 1 or 2 consecutive residual blocks, role-specialised kernels of csrc/wdsr_fwd_rs.h /
+ * wdsr_fwd_stream.h (bf16; -1 otherwise).  F = 24: every wave keeps the weights of its current phase in registers, x / weights
+ * are staged by LDS-DMA; from 256 whole images of width 48 on, the streaming kernel.  F = 32: sixteen waves, weights read from
+ * LDS at use.  The 3x3 conv runs in its dense-K form.  Same arguments as sr_wdsr_block_fwd (nblk = 1: x -> yb, the *_b / ya
+ * arguments unused) and sr_wdsr_block2_fwd (nblk = 2); results equal to theirs up to fp32 summation order, and bit-identical
+ * across this entry point's kernels (one- and two-block launches, tile, persistent and streaming forms). */
 int sr_wdsr_fwd_rs(const void* x, void* ya, void* yb, const void* wblob_a, const void* wblob_b, const float* cinit_a,
                    const float* cinit_b, void* tsave_a, void* tsave_b, int nblk, int N, int H, int W, int F, int dtype,
                    sr_stream_t stream);

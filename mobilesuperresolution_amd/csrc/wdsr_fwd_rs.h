@@ -562,7 +562,7 @@ __global__ __launch_bounds__(512) void wdsr_fwd_rs_kernel(const __bf16* __restri
 }
 
 // =============================================================================================
-// SIXTEEN waves, weights read from LDS at use (round 3 experiment, per-tile launches).  With one tile per CU a phase has 9-14
+// SIXTEEN waves, weights read from LDS at use (round 3: the route of the 32-unit network; at 24 units an experiment, variant builds).  With one tile per CU a phase has 9-14
 // pixel tiles: eight waves take them in two rounds, each a dependent LDS -> MFMA -> convert -> MFMA -> store chain, and a wave
 // that runs one tile uses each weight fragment ONCE -- loading it into a register first moves exactly the bytes a read at
 // use moves.  Here every pixel tile of a phase has its own wave (four per SIMD, 128 VGPRs), the weight fragment of an MFMA is
