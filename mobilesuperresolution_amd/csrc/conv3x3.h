@@ -9,6 +9,7 @@
 #pragma once
 #include <type_traits>
 #include "wdsr_block.h"
+#include "wdsr_fwd_rs.h"
 #include "flow_warp.h"
 
 struct C3Cfg {
@@ -29,6 +30,33 @@ struct C3Cfg {
 // trunk.  The weight-gradient launches split their workgroups the same way (first half of the grid: first trunk's images).
 struct C3Dir { long w_ds; int n_dir; };
 SR_DEV long c3_dir_off(const C3Dir& d, int n) { return (d.n_dir > 0 && n >= d.n_dir) ? d.w_ds : 0; }
+
+// a region of an NHWC bf16 image (24 channels per pixel) -> LDS rows by LDS-DMA, zero outside the image: CH = 3 chunks per row (48-byte
+// rows) or CH = 4 with the fourth chunk = [1, 0, ..] (64-byte rows whose channel 24 is the ones channel that carries the bias).  NROWS
+// rows are written, the first NLIVE of them are region pixels (row-major, RW wide, origin (y0, x0)); the destination holds whole 1 KB
+// pieces (c3_dma_elems).  Round 3: these tiles went global -> registers -> LDS before (a dependent round trip in front of the first MFMA).
+constexpr int c3_dma_elems(int nrows, int ch) { return (nrows * ch + 63) / 64 * 64 * 8; }
+template <int CH, int RW, int NLIVE, int NROWS, int NWAVES>
+SR_DEV void c3_dma_region(__bf16* dst, const __bf16* __restrict__ img, int H, int W, int y0, int x0, int tid) {
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  constexpr int NP = (NROWS * CH + 63) / 64;
+  const int lane = tid & 63, wave = tid >> 6;
+  const char* const ones = reinterpret_cast<const char*>(g_sr_const_chunks);
+  char* const d = reinterpret_cast<char*>(dst);
+  for (int p = wave; p < NP; p += NWAVES) {
+    const int idx = p * 64 + lane;
+    const int pix = idx / CH, c = idx - pix * CH;
+    const char* src = ones + 16;                        // zeros
+    if (CH == 4 && c == 3) src = ones;
+    else if (pix < NLIVE) {
+      const int py = pix / RW, px = pix - py * RW;
+      const int Y = y0 + py, X = x0 + px;
+      if (Y >= 0 && Y < H && X >= 0 && X < W) src = reinterpret_cast<const char*>(img + ((size_t)Y * W + X) * C3Cfg::CO + c * 8);
+    }
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(d + p * 1024), 16, 0, 0);
+  }
+}
 
 template <int ACT> SR_DEV float c3_act(float v) {
   if (ACT == 1) return fmaxf(v, 0.f);
@@ -384,8 +412,8 @@ struct C3Pair {
   typedef C3Cfg C;
   static constexpr int W2 = C::TW + 4, H2 = C::TH + 4, NP2 = W2 * H2;       // 20 x 20 = 400
   static constexpr int NPT_H = C::NPXH_PAD / 32;                             // 11 pixel tiles over the 18x18 region
-  static constexpr int X2_ELEMS = (NP2 + 2) * 32, T1_ELEMS = (C::NPXH_PAD + 2) * 32;
-  static constexpr int G2_ELEMS = (NP2 + 2) * C::CO, M1_ELEMS = (C::NPXH_PAD + 2) * C::CO;
+  static constexpr int X2_ELEMS = c3_dma_elems(NP2 + 2, 4), T1_ELEMS = (C::NPXH_PAD + 2) * 32;     // (x: whole DMA pieces)
+  static constexpr int G2_ELEMS = c3_dma_elems(NP2 + 2, 3), M1_ELEMS = c3_dma_elems(C::NPXH_PAD + 2, 3);   // (whole DMA pieces)
 };
 
 template <typename T>
@@ -414,35 +442,15 @@ __global__ __launch_bounds__((64 * C3Pair::NPT_H)) void c3_resblock_fwd_kernel(c
   ws2.p = WL + C::KSF * 512;
   stage_weights<T, NTHREADS>(WL, w1, C::KSF, tid);
   stage_weights<T, NTHREADS>(WL + C::KSF * 512, w2, C::KSF, tid);
-  {   // x on the 2-pixel halo: [NP2 + 2][32], 24 channels + ones channel at 24
-    constexpr int TOTAL = (P::NP2 + 2) * 4, ITER = (TOTAL + NTHREADS - 1) / NTHREADS;
-    FragT v[ITER];
+  // x on the 2-pixel halo: [NP2 + 2][32], 24 channels + ones channel at 24 (LDS-DMA)
+  c3_dma_region<4, P::W2, P::NP2, P::NP2 + 2, P::NPT_H>(reinterpret_cast<__bf16*>(X2), reinterpret_cast<const __bf16*>(x + img), H, W, ty0 - 2, tx0 - 2, tid);
+  // t image: ones channel and zero padding of every row (conv1 fills the 24 real channels of the live rows)
+  for (int idx = tid; idx < (C::NPXH_PAD + 2) * 4; idx += NTHREADS) {
+    FragT z;
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const int idx = tid + it * NTHREADS;
-      const int p = idx >> 2, c = idx & 3;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[it][j] = (T)0.f;
-      if (idx < TOTAL && p < P::NP2 && c < 3) {
-        const int py = p / P::W2, px = p - py * P::W2;
-        const int Y = ty0 - 2 + py, X = tx0 - 2 + px;
-        if (Y >= 0 && Y < H && X >= 0 && X < W) v[it] = *reinterpret_cast<const FragT*>(x + img + ((size_t)Y * W + X) * C::CO + c * 8);
-      }
-      if (c == 3) v[it][0] = (T)1.f;
-    }
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const int idx = tid + it * NTHREADS;
-      if (idx < TOTAL) *reinterpret_cast<FragT*>(X2 + idx * 8) = v[it];
-    }
-    // t image: ones channel and zero padding of every row (conv1 fills the 24 real channels of the live rows)
-    for (int idx = tid; idx < (C::NPXH_PAD + 2) * 4; idx += NTHREADS) {
-      FragT z;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) z[j] = (T)0.f;
-      if ((idx & 3) == 3) z[0] = (T)1.f;
-      *reinterpret_cast<FragT*>(T1 + idx * 8) = z;
-    }
+    for (int j = 0; j < 8; ++j) z[j] = (T)0.f;
+    if ((idx & 3) == 3) z[0] = (T)1.f;
+    *reinterpret_cast<FragT*>(T1 + idx * 8) = z;
   }
   __syncthreads();
 
@@ -518,7 +526,7 @@ __global__ __launch_bounds__((64 * C3Pair::NPT_H)) void c3_resblock_fwd_kernel(c
 struct C3Quad {
   typedef C3Cfg C;
   static constexpr int GW = C::TW + 8, GH = C::TH + 8, NG = GW * GH;         // 24 x 24 = 576
-  static constexpr int G_ELEMS = (NG + 2) * 32;
+  static constexpr int G_ELEMS = c3_dma_elems(NG + 2, 4);                   // (whole DMA pieces)
   static constexpr int NWAVES = ((GW - 2) * (GH - 2) + 31) / 32;             // conv1's pixel tiles: 16
   static constexpr int LDS_BYTES = (2 * G_ELEMS + 4 * C::KSF * 512) * 2;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -552,34 +560,14 @@ __global__ __launch_bounds__((64 * C3Quad::NWAVES)) void c3_resblock2_fwd_kernel
     ws[k].p = WL + k * C::KSF * 512;
     stage_weights<T, NTHREADS>(WL + k * C::KSF * 512, wbase + offs[k], C::KSF, tid);
   }
-  {   // x on the grid: [NG + 2][32], 24 channels + ones channel at 24; the t buffer: ones channel and zero padding of every row
-    constexpr int TOTAL = (Q::NG + 2) * 4, ITER = (TOTAL + NTHREADS - 1) / NTHREADS;
-    FragT v[ITER];
+  // x on the grid: [NG + 2][32], 24 channels + ones channel at 24 (LDS-DMA); the t buffer: ones channel and zero padding of every row
+  c3_dma_region<4, Q::GW, Q::NG, Q::NG + 2, Q::NWAVES>(reinterpret_cast<__bf16*>(XB), reinterpret_cast<const __bf16*>(x + img), H, W, ty0 - 4, tx0 - 4, tid);
+  for (int idx = tid; idx < (Q::NG + 2) * 4; idx += NTHREADS) {
+    FragT z;
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const int idx = tid + it * NTHREADS;
-      const int p = idx >> 2, c = idx & 3;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[it][j] = (T)0.f;
-      if (idx < TOTAL && p < Q::NG && c < 3) {
-        const int py = p / Q::GW, px = p - py * Q::GW;
-        const int Y = ty0 - 4 + py, X = tx0 - 4 + px;
-        if (Y >= 0 && Y < H && X >= 0 && X < W) v[it] = *reinterpret_cast<const FragT*>(x + img + ((size_t)Y * W + X) * C::CO + c * 8);
-      }
-      if (c == 3) v[it][0] = (T)1.f;
-    }
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const int idx = tid + it * NTHREADS;
-      if (idx < TOTAL) {
-        *reinterpret_cast<FragT*>(XB + idx * 8) = v[it];
-        FragT z;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) z[j] = (T)0.f;
-        if ((idx & 3) == 3) z[0] = (T)1.f;
-        *reinterpret_cast<FragT*>(TB + idx * 8) = z;
-      }
-    }
+    for (int j = 0; j < 8; ++j) z[j] = (T)0.f;
+    if ((idx & 3) == 3) z[0] = (T)1.f;
+    *reinterpret_cast<FragT*>(TB + idx * 8) = z;
   }
   __syncthreads();
 
@@ -679,12 +667,9 @@ __global__ __launch_bounds__((64 * C3Pair::NPT_H)) void c3_resblock_bwd_data_ker
   stage_weights<T, NTHREADS>(WL, w1 + (size_t)C::KSF * 512, C::KSB, tid);
   stage_weights<T, NTHREADS>(WL + C::KSB * 512, w2 + (size_t)C::KSF * 512, C::KSB, tid);
   {
-    RegionRegs<T, NTHREADS, P::W2, P::NP2 + 2, P::NP2, C::COC, C::COC, false> rg;
-    RegionRegs<T, NTHREADS, C::HW, C::NPXH_PAD + 2, C::NPXH, C::COC, C::COC, false> rm;
-    rg.load(g + img, H, W, ty0 - 2, tx0 - 2, tid);
-    rm.load(tmid + img, H, W, ty0 - 1, tx0 - 1, tid);
-    rg.store(G2, tid);
-    rm.store(M1, tid);
+    // g on the 2-pixel halo, t on the 1-pixel halo: 48-byte rows by LDS-DMA
+    c3_dma_region<3, P::W2, P::NP2, P::NP2 + 2, P::NPT_H>(reinterpret_cast<__bf16*>(G2), reinterpret_cast<const __bf16*>(g + img), H, W, ty0 - 2, tx0 - 2, tid);
+    c3_dma_region<3, C::HW, C::NPXH, C::NPXH_PAD + 2, P::NPT_H>(reinterpret_cast<__bf16*>(M1), reinterpret_cast<const __bf16*>(tmid + img), H, W, ty0 - 1, tx0 - 1, tid);
     for (int i = tid; i < (C::NPXH_PAD + 2 - C::NPXH) * C::CO; i += NTHREADS) DZ[C::NPXH * C::CO + i] = (T)0.f;   // slack rows
   }
   __syncthreads();
