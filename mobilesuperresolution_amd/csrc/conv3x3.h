@@ -58,6 +58,17 @@ SR_DEV void c3_dma_region(__bf16* dst, const __bf16* __restrict__ img, int H, in
   }
 }
 
+// B operand of k-step s of a 3x3 conv whose input sits in LDS as 48-BYTE rows (the 24 real channels: a conflict-free stride for the
+// 16-byte reads of 32 consecutive pixels, where 64-byte rows are 4-way conflicted): chunk q = 2 s + hh of the window in (tap, chunk)
+// order, four chunks per tap of which the fourth is the ONES chunk -- one constant in LDS (element offset `ones_off` from `base`;
+// the bias is the centre tap's weight on it).  `win` = element offset of the window's top-left pixel row, `rw` = region width.
+template <typename T> SR_DEV typename FragOf<T>::type c3_frag24(const T* base, int win, int rw, int ones_off, int s, int hh) {
+  const int tap = s >> 1, c0 = (2 * s) & 3;                // (s: compile-time after unrolling; chunks c0 and c0 + 1 of tap s / 2)
+  const int row = win + ((tap / 3) * rw + (tap % 3)) * C3Cfg::CO;
+  const int off = c0 == 0 ? row + hh * 8 : (hh ? ones_off : row + 16);
+  return lds_chunk<T>(base, off);
+}
+
 template <int ACT> SR_DEV float c3_act(float v) {
   if (ACT == 1) return fmaxf(v, 0.f);
   if (ACT == 2) return v > 0.f ? v : 0.1f * v;
@@ -412,7 +423,7 @@ struct C3Pair {
   typedef C3Cfg C;
   static constexpr int W2 = C::TW + 4, H2 = C::TH + 4, NP2 = W2 * H2;       // 20 x 20 = 400
   static constexpr int NPT_H = C::NPXH_PAD / 32;                             // 11 pixel tiles over the 18x18 region
-  static constexpr int X2_ELEMS = c3_dma_elems(NP2 + 2, 4), T1_ELEMS = (C::NPXH_PAD + 2) * 32;     // (x: whole DMA pieces)
+  static constexpr int X2_ELEMS = c3_dma_elems(NP2 + 2, 3), T1_ELEMS = (C::NPXH_PAD + 2) * C::CO;   // 48-byte rows (x: whole DMA pieces)
   static constexpr int G2_ELEMS = c3_dma_elems(NP2 + 2, 3), M1_ELEMS = c3_dma_elems(C::NPXH_PAD + 2, 3);   // (whole DMA pieces)
 };
 
@@ -429,10 +440,11 @@ __global__ __launch_bounds__((64 * C3Pair::NPT_H)) void c3_resblock_fwd_kernel(c
   typedef typename FragOf<T>::half_type HalfT;
   static_assert(sizeof(T) == 2, "bf16 only (LDS budget)");
   constexpr int NTHREADS = 64 * P::NPT_H;
-  __shared__ __attribute__((aligned(16))) T smem[P::X2_ELEMS + P::T1_ELEMS + 2 * C::KSF * 512];
+  __shared__ __attribute__((aligned(16))) T smem[P::X2_ELEMS + P::T1_ELEMS + 2 * C::KSF * 512 + 8];
   T* const X2 = smem;
   T* const T1 = X2 + P::X2_ELEMS;
   T* const WL = T1 + P::T1_ELEMS;
+  constexpr int ONES_OFF = P::X2_ELEMS + P::T1_ELEMS + 2 * C::KSF * 512;   // the ones chunk [1, 0 x 7]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int n = blockIdx.y, tile = blockIdx.x;
   const int ty0 = (tile / tiles_x) * C::TH, tx0 = (tile % tiles_x) * C::TW;
@@ -442,16 +454,9 @@ __global__ __launch_bounds__((64 * C3Pair::NPT_H)) void c3_resblock_fwd_kernel(c
   ws2.p = WL + C::KSF * 512;
   stage_weights<T, NTHREADS>(WL, w1, C::KSF, tid);
   stage_weights<T, NTHREADS>(WL + C::KSF * 512, w2, C::KSF, tid);
-  // x on the 2-pixel halo: [NP2 + 2][32], 24 channels + ones channel at 24 (LDS-DMA)
-  c3_dma_region<4, P::W2, P::NP2, P::NP2 + 2, P::NPT_H>(reinterpret_cast<__bf16*>(X2), reinterpret_cast<const __bf16*>(x + img), H, W, ty0 - 2, tx0 - 2, tid);
-  // t image: ones channel and zero padding of every row (conv1 fills the 24 real channels of the live rows)
-  for (int idx = tid; idx < (C::NPXH_PAD + 2) * 4; idx += NTHREADS) {
-    FragT z;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) z[j] = (T)0.f;
-    if ((idx & 3) == 3) z[0] = (T)1.f;
-    *reinterpret_cast<FragT*>(T1 + idx * 8) = z;
-  }
+  // x on the 2-pixel halo: [NP2 + 2][24] (LDS-DMA); the ones chunk
+  c3_dma_region<3, P::W2, P::NP2, P::NP2 + 2, P::NPT_H>(reinterpret_cast<__bf16*>(X2), reinterpret_cast<const __bf16*>(x + img), H, W, ty0 - 2, tx0 - 2, tid);
+  if (tid < 8) smem[ONES_OFF + tid] = tid == 0 ? (T)1.f : (T)0.f;
   __syncthreads();
 
   // ---- conv1 + ReLU on the tile + 1-pixel halo ----
@@ -464,8 +469,7 @@ __global__ __launch_bounds__((64 * C3Pair::NPT_H)) void c3_resblock_fwd_kernel(c
     f32x16 acc = zero16();
 #pragma unroll
     for (int s = 0; s < C::KSF; ++s) {
-      const int q = 2 * s + hh, tap = q >> 2, c = q & 3;
-      acc = mma16<T>(ws1.get(s, lane), lds_chunk<T>(X2, (base2 + (tap / 3) * P::W2 + (tap % 3)) * 32 + c * 8), acc);
+      acc = mma16<T>(ws1.get(s, lane), c3_frag24<T>(smem, base2 * C::CO, P::W2, ONES_OFF, s, hh), acc);
     }
     if (live) {
       const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
@@ -476,28 +480,25 @@ __global__ __launch_bounds__((64 * C3Pair::NPT_H)) void c3_resblock_fwd_kernel(c
         HalfT v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = inimg ? (T)c3_act<1>(acc[4 * g + j]) : (T)0.f;
-        *reinterpret_cast<HalfT*>(T1 + hp1 * 32 + g * 8 + hh * 4) = v;
+        *reinterpret_cast<HalfT*>(T1 + hp1 * C::CO + g * 8 + hh * 4) = v;
         if (core) *reinterpret_cast<HalfT*>(tmid + img + ((size_t)Y * W + X) * C::CO + g * 8 + hh * 4) = v;
       }
     }
   }
   __syncthreads();
 
-  // ---- conv2 + residual on the core ----
+  // ---- conv2 + residual on the core (32 consecutive pixels of the row-major core per wave: conflict-free rows) ----
   if (wave < C::NPT_O) {
-    const int ot = wave;
-    const int oy = (ot / (C::TW / 8)) * 4 + (r >> 3), ox = (ot % (C::TW / 8)) * 8 + (r & 7);
+    const int pc = wave * 32 + r;
+    const int oy = pc / C::TW, ox = pc - oy * C::TW;
     const int hbase = oy * C::HW + ox;
     f32x16 acc = zero16();
 #pragma unroll
-    for (int s = 0; s < C::KSF; ++s) {
-      const int q = 2 * s + hh, tap = q >> 2, c = q & 3;
-      acc = mma16<T>(ws2.get(s, lane), lds_chunk<T>(T1, (hbase + (tap / 3) * C::HW + (tap % 3)) * 32 + c * 8), acc);
-    }
+    for (int s = 0; s < C::KSF; ++s) acc = mma16<T>(ws2.get(s, lane), c3_frag24<T>(smem, P::X2_ELEMS + hbase * C::CO, C::HW, ONES_OFF, s, hh), acc);
     const int Y = ty0 + oy, X = tx0 + ox;
     if (Y < H && X < W) {
       const size_t o = img + ((size_t)Y * W + X) * C::CO;
-      const T* xr = X2 + ((oy + 2) * P::W2 + ox + 2) * 32;
+      const T* xr = X2 + ((oy + 2) * P::W2 + ox + 2) * C::CO;
 #pragma unroll
       for (int g = 0; g < C::COC; ++g) {
         const HalfT rv = *reinterpret_cast<const HalfT*>(xr + g * 8 + hh * 4);
@@ -526,9 +527,9 @@ __global__ __launch_bounds__((64 * C3Pair::NPT_H)) void c3_resblock_fwd_kernel(c
 struct C3Quad {
   typedef C3Cfg C;
   static constexpr int GW = C::TW + 8, GH = C::TH + 8, NG = GW * GH;         // 24 x 24 = 576
-  static constexpr int G_ELEMS = c3_dma_elems(NG + 2, 4);                   // (whole DMA pieces)
+  static constexpr int G_ELEMS = c3_dma_elems(NG + 2, 3);                   // 48-byte rows, whole DMA pieces
   static constexpr int NWAVES = ((GW - 2) * (GH - 2) + 31) / 32;             // conv1's pixel tiles: 16
-  static constexpr int LDS_BYTES = (2 * G_ELEMS + 4 * C::KSF * 512) * 2;
+  static constexpr int LDS_BYTES = (2 * G_ELEMS + 4 * C::KSF * 512 + 8) * 2;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -544,7 +545,8 @@ __global__ __launch_bounds__((64 * C3Quad::NWAVES)) void c3_resblock2_fwd_kernel
   typedef typename FragOf<T>::half_type HalfT;
   static_assert(sizeof(T) == 2, "bf16 only (LDS budget)");
   constexpr int NTHREADS = 64 * Q::NWAVES;
-  __shared__ __attribute__((aligned(16))) T smem[2 * Q::G_ELEMS + 4 * C::KSF * 512];
+  __shared__ __attribute__((aligned(16))) T smem[2 * Q::G_ELEMS + 4 * C::KSF * 512 + 8];
+  constexpr int ONES_OFF = 2 * Q::G_ELEMS + 4 * C::KSF * 512;               // the ones chunk [1, 0 x 7]
   T* const XB = smem;                       // x on the grid, then y_a in place
   T* const TB = XB + Q::G_ELEMS;            // t_a, then t_b
   T* const WL = TB + Q::G_ELEMS;
@@ -560,15 +562,9 @@ __global__ __launch_bounds__((64 * C3Quad::NWAVES)) void c3_resblock2_fwd_kernel
     ws[k].p = WL + k * C::KSF * 512;
     stage_weights<T, NTHREADS>(WL + k * C::KSF * 512, wbase + offs[k], C::KSF, tid);
   }
-  // x on the grid: [NG + 2][32], 24 channels + ones channel at 24 (LDS-DMA); the t buffer: ones channel and zero padding of every row
-  c3_dma_region<4, Q::GW, Q::NG, Q::NG + 2, Q::NWAVES>(reinterpret_cast<__bf16*>(XB), reinterpret_cast<const __bf16*>(x + img), H, W, ty0 - 4, tx0 - 4, tid);
-  for (int idx = tid; idx < (Q::NG + 2) * 4; idx += NTHREADS) {
-    FragT z;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) z[j] = (T)0.f;
-    if ((idx & 3) == 3) z[0] = (T)1.f;
-    *reinterpret_cast<FragT*>(TB + idx * 8) = z;
-  }
+  // x on the grid: [NG + 2][24] (LDS-DMA); the ones chunk
+  c3_dma_region<3, Q::GW, Q::NG, Q::NG + 2, Q::NWAVES>(reinterpret_cast<__bf16*>(XB), reinterpret_cast<const __bf16*>(x + img), H, W, ty0 - 4, tx0 - 4, tid);
+  if (tid < 8) smem[ONES_OFF + tid] = tid == 0 ? (T)1.f : (T)0.f;
   __syncthreads();
 
   // one conv stage: output region [LO, GW - LO)^2 of the grid, one pixel tile per wave; IN -> acc; the epilogue is the caller's
@@ -584,13 +580,10 @@ __global__ __launch_bounds__((64 * C3Quad::NWAVES)) void c3_resblock2_fwd_kernel
     X = tx0 - 4 + gx;
     inimg = Y >= 0 && Y < H && X >= 0 && X < W;
     core = inimg && gy >= 4 && gy < 4 + C::TH && gx >= 4 && gx < 4 + C::TW;
-    const int base = gp - Q::GW - 1;
+    const int win = (int)(IN - smem) + (gp - Q::GW - 1) * C::CO;
     f32x16 acc = zero16();
 #pragma unroll
-    for (int s = 0; s < C::KSF; ++s) {
-      const int q = 2 * s + hh, tap = q >> 2, c = q & 3;
-      acc = mma16<T>(wk.get(s, lane), lds_chunk<T>(IN, (base + (tap / 3) * Q::GW + (tap % 3)) * 32 + c * 8), acc);
-    }
+    for (int s = 0; s < C::KSF; ++s) acc = mma16<T>(wk.get(s, lane), c3_frag24<T>(smem, win, Q::GW, ONES_OFF, s, hh), acc);
     return acc;
   };
   auto relu_stage = [&](auto lo_c, const T* IN, T* OUT, const WSrc<T, true>& wk, T* tmid) {
@@ -605,7 +598,7 @@ __global__ __launch_bounds__((64 * C3Quad::NWAVES)) void c3_resblock2_fwd_kernel
         HalfT v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = inimg ? (T)c3_act<1>(acc[4 * g + j]) : (T)0.f;
-        *reinterpret_cast<HalfT*>(OUT + gp * 32 + g * 8 + hh * 4) = v;
+        *reinterpret_cast<HalfT*>(OUT + gp * C::CO + g * 8 + hh * 4) = v;
         if (core) *reinterpret_cast<HalfT*>(tmid + img + ((size_t)Y * W + X) * C::CO + g * 8 + hh * 4) = v;
       }
     }
@@ -619,11 +612,11 @@ __global__ __launch_bounds__((64 * C3Quad::NWAVES)) void c3_resblock2_fwd_kernel
     if (live) {
 #pragma unroll
       for (int g = 0; g < C::COC; ++g) {
-        const HalfT rv = *reinterpret_cast<const HalfT*>(RES + gp * 32 + g * 8 + hh * 4);
+        const HalfT rv = *reinterpret_cast<const HalfT*>(RES + gp * C::CO + g * 8 + hh * 4);
         HalfT v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = inimg ? (T)(acc[4 * g + j] + (float)rv[j]) : (T)0.f;
-        if (to_lds) *reinterpret_cast<HalfT*>(RES + gp * 32 + g * 8 + hh * 4) = v;       // in place: this pixel's own row
+        if (to_lds) *reinterpret_cast<HalfT*>(RES + gp * C::CO + g * 8 + hh * 4) = v;    // in place: this pixel's own row
         if (core) *reinterpret_cast<HalfT*>(yout + img + ((size_t)Y * W + X) * C::CO + g * 8 + hh * 4) = v;
       }
     }
