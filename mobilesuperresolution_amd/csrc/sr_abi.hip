@@ -382,7 +382,7 @@ extern "C" int sr_tail_fwd(const void* feat, const float* x, float* out, const v
   if (!feat || !x || !out || !wblob || N <= 0 || H <= 0 || W <= 0 || N > 65535) return -2;
   hipStream_t st = (hipStream_t)stream;
 #define CALLR(T, F_, R_) { typedef EndsCfg<F_, R_> E; int tx; dim3 g = tile_grid<E>(N, H, W, &tx); \
-    hipLaunchKernelGGL((sr_tail_fwd_kernel<T, F_, R_>), g, dim3(256), 0, st, (const T*)feat, x, out, (const T*)wblob, mean, H, W, tx); }
+    hipLaunchKernelGGL((sr_tail_fwd_kernel<T, F_, R_>), g, dim3(SR_TAIL_FWD_THREADS), 0, st, (const T*)feat, x, out, (const T*)wblob, mean, H, W, tx); }
 #define CALL(T, F_) SR_DISPATCH_R(CALLR, T, F_)
   SR_DISPATCH_TF(CALL)
 #undef CALL

@@ -259,8 +259,10 @@ __global__ __launch_bounds__(256) void sr_head_fwd_kernel(const float* __restric
 // tail forward: out = PixelShuffle_R( conv3x3(feat; Wt) + conv5x5(x - mean; Ws) + bt + bs ) + mean
 // (the three constants ride on the image's ones channel at the skip's centre tap)
 // ---------------------------------------------------------------------------------------------
+// eight waves (round 3): the tile's nine pixel tiles are two rounds instead of three, two waves per SIMD (four waves before: one per SIMD)
+constexpr int SR_TAIL_FWD_THREADS = 512;
 template <typename T, int F, int R>
-__global__ __launch_bounds__(256) void sr_tail_fwd_kernel(const T* __restrict__ feat, const float* __restrict__ ximg,
+__global__ __launch_bounds__(SR_TAIL_FWD_THREADS) void sr_tail_fwd_kernel(const T* __restrict__ feat, const float* __restrict__ ximg,
                                                           float* __restrict__ out, const T* __restrict__ wblob,
                                                           float mean, int H, int W, int tiles_x) {
   typedef EndsCfg<F, R> E;
@@ -272,12 +274,12 @@ __global__ __launch_bounds__(256) void sr_tail_fwd_kernel(const T* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int n = blockIdx.y, tile = blockIdx.x;
   const int ty0 = (tile / tiles_x) * E::TH, tx0 = (tile % tiles_x) * E::TW;
-  stage_halo<T, E, F>(FT, feat + (size_t)n * H * W * F, H, W, ty0, tx0, tid);
-  stage_img<T, E, 2>(smem + XI0, ximg + (size_t)n * 3 * H * W, mean, H, W, ty0, tx0, tid);
+  stage_halo<T, E, F, SR_TAIL_FWD_THREADS>(FT, feat + (size_t)n * H * W * F, H, W, ty0, tx0, tid);
+  stage_img<T, E, 2, SR_TAIL_FWD_THREADS>(smem + XI0, ximg + (size_t)n * 3 * H * W, mean, H, W, ty0, tx0, tid);
   __syncthreads();
   constexpr bool HOIST = (sizeof(T) == 2) && (E::NT * E::KST <= 42);
   const T* const wblob0 = wblob;
-  for (int ot = wave; ot < E::NPT_O; ot += 4) {
+  for (int ot = wave; ot < E::NPT_O; ot += SR_TAIL_FWD_THREADS / 64) {
     wblob = weights_for_tile<HOIST>(wblob0);
     const int oy = (ot / (E::TW / 8)) * 4 + (r >> 3), ox = (ot % (E::TW / 8)) * 8 + (r & 7);
     const int hbase = oy * E::HW + ox;
