@@ -238,6 +238,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # clock settle: the driver's default (--warmup 5 --steps 20) is 9 ms of GPU work right after process start, shorter than the
+    # GPU's clock ramp; ~40 ms of untimed forward passes (inference, nothing saved) come first so that the warm-up and timed steps
+    # run at the clocks a training run sees.  Reported as `clock_settle_forwards`; SR_BENCH_SETTLE=0 turns it off.
+    settle = int(os.environ.get("SR_BENCH_SETTLE", 400))
+    with torch.no_grad():
+        for _ in range(settle):
+            model(x)
     for _ in range(args.warmup):
         step()
     sync()
@@ -452,6 +459,7 @@ def main():
                              else ", one gradient all-reduce (avg, 0.77 MB) on the compute stream before the Adam kernel") if use_ddp else ", one C call"))
                           if fused else "DistributedDataParallel wrapper (two gradient segments): forward / F.l1_loss / backward + "
                                         "bucketed all-reduce / torch Adam",
+            "clock_settle_forwards": settle,
             "per_step_ms": {"n": nd, "median": round(dist_ms[nd // 2], 4), "p10": round(dist_ms[nd // 10], 4),
                             "p90": round(dist_ms[(nd * 9) // 10], 4)},
             "ms_per_step_with_item_sync": round(item_ms, 4),
