@@ -161,6 +161,29 @@ def stream_ptr(device=None) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+class _NoGuard:
+    """`with` target that does nothing"""
+    __slots__ = ()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOGUARD = _NoGuard()
+
+
+def device_guard(device):
+    """`with torch.cuda.device(device)` only when `device` is not the current one already: the context manager costs ~10 us of host time
+    per use, and the training loop of the reference enters four of them per step between its per-step `loss.item()` syncs"""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NOGUARD
+    return torch.cuda.device(idx)
+
+
 def check(rc: int, what: str):
     if rc != 0:
         kind = {-1: "unsupported geometry/dtype", -2: "bad argument"}.get(rc, f"hipError_t {rc}")

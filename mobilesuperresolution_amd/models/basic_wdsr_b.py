@@ -288,7 +288,7 @@ class BASIC_MODEL(nn.Module):
             key = (flat.data_ptr(), flat._version)
         static = getattr(self, "assume_static_weights", False) and not save_acts and st.packed_key == key
         flags = (1 if save_acts else 0) | (2 if static else 0)
-        with torch.cuda.device(x.device):
+        with L.device_guard(x.device):
             L.launch("sr_wdsr_net_forward", L.lib().sr_wdsr_net_forward, ctypes.byref(net), flags, L.stream_ptr(x.device))
         st.packed_key = key
         return out, acts, side
@@ -340,7 +340,7 @@ class BASIC_MODEL(nn.Module):
         net.tsave = side.data_ptr() if side is not None else None
         net.dtsave = dtsave.data_ptr() if dtsave is not None else None
         net.hr, net.loss_kind, net.loss_gscale = hr.data_ptr(), self._LOSS_KINDS[kind], self._gscale(weight, out.numel())
-        with torch.cuda.device(x.device):
+        with L.device_guard(x.device):
             L.launch("sr_wdsr_net_backward", L.lib().sr_wdsr_net_backward, ctypes.byref(net), L.stream_ptr(x.device))
         return net, out, gflat, (acts, grads, side, dtsave)
 
@@ -366,7 +366,7 @@ class BASIC_MODEL(nn.Module):
         net.tsave = side.data_ptr() if side is not None else None
         net.dtsave = dtsave.data_ptr() if dtsave is not None else None
         net.hr, net.loss_kind, net.loss_gscale = hr.data_ptr(), self._LOSS_KINDS[kind], self._gscale(1.0, sr.numel())
-        with torch.cuda.device(x.device):
+        with L.device_guard(x.device):
             if st.packed_key != node.packed_key:     # another forward re-packed the per-device blobs meanwhile: pack ours again
                 L.launch("sr_wdsr_net_forward", L.lib().sr_wdsr_net_forward, ctypes.byref(net), 4, L.stream_ptr(x.device))
                 st.packed_key = node.packed_key
@@ -450,7 +450,7 @@ class BASIC_MODEL(nn.Module):
         pg = process_group                                   # (given explicitly: the data-parallel route even on one rank)
         if pg is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             pg = dist.group.WORLD
-        with torch.cuda.device(x.device):
+        with L.device_guard(x.device):
             sp = L.stream_ptr(x.device)
             # Data-parallel: `overlap` = all-reduce the late half's gradient under the early half's backward.  That costs two
             # half-depth weight-gradient launches per kernel and a second slab reduction (+29 us at C2) and leaves the second
@@ -573,7 +573,7 @@ class _NetFunction(torch.autograd.Function):
         dtsave = torch.empty_like(ctx.tsave) if ctx.tsave is not None else None
         net.tsave = ctx.tsave.data_ptr() if ctx.tsave is not None else None
         net.dtsave = dtsave.data_ptr() if dtsave is not None else None
-        with torch.cuda.device(x.device):
+        with L.device_guard(x.device):
             if st.packed_key != ctx.packed_key:      # another forward re-packed the per-device blobs meanwhile: pack ours again
                 L.launch("sr_wdsr_net_forward", L.lib().sr_wdsr_net_forward, ctypes.byref(net), 4, L.stream_ptr(x.device))
                 st.packed_key = ctx.packed_key
@@ -604,7 +604,7 @@ class _NetLoFunction(torch.autograd.Function):
         model, sh = ctx.model, ctx.shared
         (flat_lo,) = ctx.saved_tensors
         x = sh.x
-        with torch.cuda.device(x.device):
+        with L.device_guard(x.device):
             L.launch("sr_wdsr_net_backward_part", L.lib().sr_wdsr_net_backward_part, ctypes.byref(sh.net), 2, L.stream_ptr(x.device))
         k = flat_lo.numel()
         return None, sh.gflat[:k], None, None
@@ -638,7 +638,7 @@ class _NetHiFunction(torch.autograd.Function):
         net.dtsave = sh.dtsave.data_ptr() if sh.dtsave is not None else None
         sh.net = net
         ctx.dout = dout                                       # keep the HR gradient alive until the early half has run
-        with torch.cuda.device(x.device):
+        with L.device_guard(x.device):
             if st.packed_key != sh.packed_key:
                 L.launch("sr_wdsr_net_forward", L.lib().sr_wdsr_net_forward, ctypes.byref(net), 4, L.stream_ptr(x.device))
                 st.packed_key = sh.packed_key
@@ -657,7 +657,7 @@ class _NetLossFunction(torch.autograd.Function):
         net, out, gflat, _keep = model._loss_backward_impl(x, hr, flat, kind, weight)
         loss = torch.empty((), dtype=torch.float32, device=x.device)
         st = model._state(x.device)
-        with torch.cuda.device(x.device):
+        with L.device_guard(x.device):
             L.launch("sr_loss_value", L.lib().sr_loss_value, st.loss_part.data_ptr(), st.wgs_tail, weight / out.numel(),
                      loss.data_ptr(), L.stream_ptr(x.device))
         ctx.save_for_backward(gflat)

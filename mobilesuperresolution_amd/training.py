@@ -80,7 +80,7 @@ class _FoldedCriterion(torch.autograd.Function):
     def forward(ctx, sr, hr, node, fold, kind):
         payload, loss_part = fold.run(node, sr, hr, kind)
         loss = torch.empty((), dtype=torch.float32, device=sr.device)
-        with torch.cuda.device(sr.device):
+        with L.device_guard(sr.device):
             L.launch("sr_loss_value", L.lib().sr_loss_value, loss_part.data_ptr(), loss_part.numel(), 1.0 / sr.numel(), loss.data_ptr(),
                      L.stream_ptr(sr.device))
         ctx.node = node
@@ -164,7 +164,7 @@ class Adam(torch.optim.Optimizer):
                 t = int(state["step"])
                 bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
                 scal = L.AdamScalars(1.0 - b1, b2, 1.0 - b2, math.sqrt(bc2), eps, -(lr / bc1))
-                with torch.cuda.device(p.device):
+                with L.device_guard(p.device):
                     L.launch("sr_adam_step", lib.sr_adam_step, p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(),
                              state["exp_avg_sq"].data_ptr(), p.numel(), ctypes.byref(scal), None, 0, 0.0, None, L.stream_ptr(p.device))
                 try:
