@@ -198,3 +198,19 @@ def test_drop_in_loss_other_uses_of_the_output_still_work():
     with torch.no_grad():
         m.eval()
         assert float(crit(m(x), hr)) > 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_scale_by_device_scalar_forms_the_product_in_fp32(dtype):
+    """sr_scale_by (what a folded loss's data gradient is multiplied with: the trainer's loss weight as autograd's device scalar):
+    y = round_to_dtype(fp32(x) * scale), ragged length, 16-byte aligned buffers"""
+    from mobilesuperresolution_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    for n in (8, 2048, 2048 * 3 + 5 * 8, 100003 * 8):
+        x = torch.randn(n, generator=g).cuda().to(dtype)
+        s = torch.tensor([0.3712345], device="cuda")
+        y = torch.full_like(x, float("nan"))
+        L.check(L.lib().sr_scale_by(y.data_ptr(), x.data_ptr(), n, s.data_ptr(), L.DTYPE_CODE[dtype], L.stream_ptr()), "sr_scale_by")
+        torch.cuda.synchronize()
+        assert torch.equal(y, (x.float() * s).to(dtype))
+    assert L.lib().sr_scale_by(None, x.data_ptr(), 8, s.data_ptr(), 1, L.stream_ptr()) == -2
