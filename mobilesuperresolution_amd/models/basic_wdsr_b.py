@@ -305,7 +305,8 @@ class BASIC_MODEL(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._check_input(x)
-        x = x.contiguous().float()
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.contiguous().float()
         if self.grad_segments == 2:
             if torch.is_grad_enabled() and (self.flat_lo.requires_grad or self.flat_hi.requires_grad):
                 shared = _Shared()

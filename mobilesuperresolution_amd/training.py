@@ -139,6 +139,20 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
 
+    def zero_grad(self, set_to_none: bool = True):
+        """torch.optim.Optimizer.zero_grad's effect without its per-call bookkeeping (profiler record, foreach grouping: ~12 us of host
+        time for one parameter -- in the reference's loop that sits between the per-step `loss.item()` sync and the forward's first
+        launch, i.e. it is GPU idle time)"""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    if set_to_none:
+                        p.grad = None
+                    else:
+                        p.grad.detach_()
+                        p.grad.requires_grad_(False)
+                        p.grad.zero_()
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
