@@ -145,4 +145,29 @@ for batch in (32, 64, 128, 256, 512):
     sweep[str(batch)] = {"single_us": round(u1 * 1e6, 2), "single_GB_s": round(alg / u1 / 1e9), "pair_us": round(u2 * 1e6, 2),
                          "pair_GB_s": round(2 * alg / u2 / 1e9)}
 out["block_fwd_batch_sweep_bf16"] = sweep
+
+# f3 / f4 rows of SURVEY section 8: the device input pipeline (32 training items cut from a resident uint8 cache: crop, flips, axis swap,
+# uint8 -> float, LR 48x48 + HR 192x192) and the evaluation metrics on a batch of 32 HR patches
+try:
+    import random
+    from mobilesuperresolution_amd.datasets import DevicePatchCache
+    from mobilesuperresolution_amd import metrics as MET
+    gimg = torch.Generator().manual_seed(5)
+    hr_chw = [(torch.rand(3, 1356 + 12 * i, 2040, generator=gimg) * 255) for i in range(4)]      # DIV2K-sized images
+    lr_imgs = [torch.nn.functional.avg_pool2d(h, 4).byte().permute(1, 2, 0).contiguous() for h in hr_chw]
+    hr_imgs = [h.byte().permute(1, 2, 0).contiguous() for h in hr_chw]
+    cache = DevicePatchCache(lr_imgs, hr_imgs, 48, 4, ignored_boundary_size=0, num_patches=8, device=dev)
+    rng = random.Random(0)
+    idx = list(range(32))
+    tb = timeit(lambda: cache.batch(idx, rng), n=30, warm=5)
+    nbytes = 32 * 3 * (48 * 48 + 192 * 192) * (1 + 4)                   # uint8 read + fp32 written
+    out["f3_patch_batch_32_items"] = {"us_incl_host_draws": round(tb * 1e6, 1), "GB_s_algorithmic": round(nbytes / tb / 1e9, 1)}
+    sr_ = torch.rand(32, 3, 192, 192, device=dev)
+    hr_ = torch.rand(32, 3, 192, 192, device=dev)
+    tp = timeit(lambda: MET.psnr(sr_, hr_), n=30, warm=5)
+    ty = timeit(lambda: MET.psnr_y(sr_, hr_), n=30, warm=5)
+    out["f4_metrics_32x3x192x192"] = {"psnr_us": round(tp * 1e6, 1), "psnr_y_us": round(ty * 1e6, 1),
+                                      "psnr_GB_s_algorithmic": round(2 * sr_.numel() * 4 / tp / 1e9, 1)}
+except Exception as e:
+    out["f3_f4_rows"] = {"error": repr(e)}
 print(json.dumps(out))
