@@ -51,9 +51,11 @@ int sr_wdsr_block2_fwd(const void* x, void* ya, void* yb, const void* wblob_a, c
  * basic_wdsr_b.py:131-137) for the core pixels, tile-local [N][tiles][288][24] bf16, for
  * sr_wdsr_block_wgrad_saved. */
 
-/* Backward-data of two consecutive blocks in one launch (bf16, F = 24 only; -1 otherwise): block A feeds
+/* Backward-data of two consecutive blocks in one launch (bf16, F = 24 or 32; -1 otherwise): block A feeds
  * block B.  xa / xb = the blocks' inputs, dyb = gradient at B's output; writes dxb (= gradient at A's
- * output, which the weight-gradient kernels read) and dxa.  Bit-identical to two sr_wdsr_block_bwd_data calls. */
+ * output, which the weight-gradient kernels read) and dxa.  F = 32: bit-identical to two sr_wdsr_block_bwd_data calls
+ * (csrc/wdsr_bwd_pair_lds.h); F = 24: equal to them up to fp32 summation order (csrc/wdsr_bwd_rs.h: the skip term enters the sum
+ * first). */
 int sr_wdsr_block2_bwd_data(const void* xa, const void* xb, const void* dyb, void* dxb, void* dxa,
                             const void* wblob_a, const void* wblob_b, const float* cinit_a, const float* cinit_b,
                             void* dtsave_a, void* dtsave_b, int N, int H, int W, int F, int dtype, sr_stream_t stream);

@@ -6,6 +6,7 @@
 #include "wdsr_fwd_rs.h"
 #include "wdsr_fwd_stream.h"
 #include "wdsr_bwd_rs.h"
+#include "wdsr_bwd_pair_lds.h"
 #include "wdsr_wgrad_rs.h"
 #include "wdsr_ends.h"
 #include "wdsr_prep.h"
@@ -248,9 +249,17 @@ extern "C" int sr_wdsr_block2_bwd_data(const void* xa, const void* xb, const voi
                                        void* dtb, int N, int H, int W, int F, int dtype, sr_stream_t stream) {
   if (!xa || !xb || !dyb || !dxb || !dxa || !wa || !wb || !cia || !cib || N <= 0 || H <= 0 || W <= 0 || N > 65535)
     return -2;
-  if (F != 24 || dtype != SR_DTYPE_BF16) return -1;
+  if ((F != 24 && F != 32) || dtype != SR_DTYPE_BF16) return -1;
   typedef BlockCfg<24, 144, 20> C;
   const int tiles_x = (W + C::TW - 1) / C::TW, tiles_y = (H + C::TH - 1) / C::TH;
+  if (F == 32) {                                       // 32 units: twelve waves, fragments from LDS at use (csrc/wdsr_bwd_pair_lds.h)
+    typedef BwdPairCfg<32, 192, 26> R;
+    hipLaunchKernelGGL((wdsr_bwd_pair_lds_kernel<32, 192, 26>), dim3(tiles_x * tiles_y, N), dim3(R::NTHREADS), 0, (hipStream_t)stream,
+                       (const __bf16*)xa, (const __bf16*)xb, (const __bf16*)dyb, (__bf16*)dxb, (__bf16*)dxa, (const __bf16*)wa,
+                       (const __bf16*)wb, cia, cib, (__bf16*)dta, (__bf16*)dtb, H, W, tiles_x);
+    SR_HIP_CHECK_LAUNCH();
+    return 0;
+  }
   if (!SR_AB("SR_BWD2_OLD")) {                         // round 3: 8 waves, register-resident weights (csrc/wdsr_bwd_rs.h)
     hipLaunchKernelGGL((wdsr_bwd_rs_kernel<24, 144, 20>), dim3(tiles_x * tiles_y, N), dim3(512), 0, (hipStream_t)stream, (const __bf16*)xa,
                        (const __bf16*)xb, (const __bf16*)dyb, (__bf16*)dxb, (__bf16*)dxa, (const __bf16*)wa, (const __bf16*)wb, (__bf16*)dta,
@@ -946,7 +955,8 @@ static int net_backward_part_impl(const sr_wdsr_net_t* n, int part, sr_stream_t 
   const long act_e = (long)n->N * n->H * n->W * n->F;
   char* acts = (char*)n->acts;
   char* grads = (char*)n->grads;
-  const bool pairs = net_uses_pairs(n);
+  const bool pairs = net_uses_pairs(n) ||
+                     (n->F == 32 && n->dtype == SR_DTYPE_BF16 && net_tiles(n) <= 384 && !getenv("SR_F32_ONE_BLOCK"));   // (as the forward)
   const bool saved = net_saves_side_images(n, true);
   const size_t side = side_image_bytes(n);
   int split = part == 0 ? 0 : n->nb_split;
