@@ -420,3 +420,32 @@ def test_32_units_two_blocks_per_forward_launch_equal_one_block_kernels(monkeypa
     torch.nn.functional.l1_loss(ya, hr).backward()
     assert ((yp - ya.detach()).norm() / ya.detach().norm()).item() <= 2e-2
     assert ((gp - a.flat.grad).norm() / a.flat.grad.norm()).item() <= 6e-2
+
+
+@pytest.mark.parametrize("units", [24, 32])
+def test_overlapped_two_part_backward_equals_one_part(units):
+    """the data-parallel step with the gradient all-reduce in two halves (backward_part 1 / 2, pair launches on either side of the
+    split) against the one-call step, on a one-rank RCCL group, 24 and 32 units: the same gradients up to the summation order of the
+    weight-gradient slabs (a half-depth part spreads its layers over other workgroups)"""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29541"
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        g = torch.Generator().manual_seed(31)
+        x = torch.rand(4, 3, 24, 36, generator=g).cuda()
+        hr = torch.rand(4, 3, 96, 144, generator=g).cuda()
+        flats = []
+        for overlap in (True, False):
+            torch.manual_seed(2)
+            m = _model(_ns(num_blocks=8, num_residual_units=units, hot_dtype="bf16")).train()
+            st = m.make_train_state(lr=1e-3)
+            for _ in range(2):
+                loss = m.train_step(x, hr, st, process_group=dist.group.WORLD, overlap=overlap)
+            assert torch.isfinite(loss)
+            flats.append(m.flat.detach().clone())
+        d = (flats[0] - flats[1]).abs()
+        scale = float(flats[1].abs().max())
+        assert float((d > 2e-5 * scale + 2e-6).float().mean()) <= 1e-3 and float(d.max()) <= 0.1 * 2 * 1e-3, (float(d.max()), scale)
+    finally:
+        dist.destroy_process_group()
